@@ -1,0 +1,132 @@
+"""The CPU oracle (oracle/) against the golden vectors captured from the reference itself
+(tests/golden/make_golden.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from bvcodec import synth
+from oracle import bigvgan as obig, bvrnn as obv, codec as ocodec, frontend as ofe, melbank as omel
+
+torch.set_num_threads(8)
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+# ----------------------------------------------------------------- A4: mel filterbank (librosa restated)
+def test_melbank_against_independent_implementation():
+    """librosa is absent; pin the restated Slaney construction against transformers' own."""
+    from transformers.audio_utils import mel_filter_bank
+    ours = omel.mel_filterbank(22050, 1024, 80, 0, 8000)
+    theirs = mel_filter_bank(513, 80, 0.0, 8000.0, 22050, norm="slaney", mel_scale="slaney").T
+    assert ours.shape == (80, 513) and ours.dtype == np.float32
+    assert np.abs(ours - theirs).max() < 5e-9
+    nz = np.count_nonzero(ours)
+    assert nz == 727 and np.nonzero(ours.sum(0))[0].max() == 371
+    assert abs(float(ours.astype(np.float64).sum()) - 3.713688) < 1e-5
+
+
+def test_hann_is_periodic():
+    w = omel.hann_periodic(1024)
+    assert w[0] == 0.0 and w[512] == 1.0 and abs(w[1] - w[1023]) < 1e-9
+
+
+# ----------------------------------------------------------------- A3: front-end
+@pytest.mark.parametrize("name", ["g1_mel", "g1_mel_short"])
+def test_frontend_matches_reference(name):
+    g = load_golden(name)
+    mel = ofe.log_mel(t(g["x"]) * ofe.SCALING)
+    assert mel.shape == g["mel"].shape
+    assert np.abs(mel.numpy() - g["mel"]).max() <= 2e-6
+    # float64 truth agrees with the float32 reference to float32 accuracy
+    mel64 = ofe.log_mel(t(g["x"]).double() * ofe.SCALING, dtype=torch.float64)
+    # (in quiet bands of tonal input the float32 FFT's own rounding noise dominates: compare linearly)
+    lin64, lin32 = np.exp(mel64.numpy()), np.exp(g["mel"].astype(np.float64))
+    assert (np.abs(lin64 - lin32) <= 1e-6 + 3e-6 * lin64).all()
+
+
+# ----------------------------------------------------------------- A5/A6/A7: BVRNN
+@pytest.mark.parametrize("tag,h_dim,var_bit", [("h1024_var", 1024, True), ("h1024_fix", 1024, False),
+                                              ("h64_var", 64, True)])
+def test_bvrnn_matches_reference(tag, h_dim, var_bit, conf_var):
+    g = load_golden(f"g3_bvrnn_{tag}")
+    c = dict(conf_var); c["h_dim"] = h_dim; c["var_bit"] = var_bit
+    sd = synth.bvrnn_state_dict(c, seed=int(g["seed"]))
+    B = g["y"].shape[0]
+    r = obv.encode(sd, t(g["y"]), t(g["bits"]), torch.zeros(B, h_dim), var_bit=var_bit)
+    assert np.array_equal(r["codes"].numpy(), g["codes"])                # bit-exact codes
+    assert set(np.unique(g["codes"])) <= {0.0, 0.5, 1.0}
+    assert np.abs(r["prob"].numpy() - g["prob"]).max() < 1e-6
+    assert np.abs(r["all_h"].numpy() - g["all_h"]).max() < 2e-6
+    assert np.array_equal(g["all_h"][:, 0], np.zeros_like(g["all_h"][:, 0]))   # state BEFORE update
+    d = obv.decode(sd, t(g["codes"]), torch.zeros(B, h_dim))
+    assert np.abs(d["mel"].numpy() - g["mel_hat"]).max() < 2e-5
+    assert np.abs(d["h_last"].numpy() - g["h_T"]).max() < 2e-6
+    # teacher-forced: every frame restarted from the reference's own state gives the same bits
+    r2 = obv.encode(sd, t(g["y"]), t(g["bits"]), torch.zeros(B, h_dim), var_bit=var_bit,
+                    forced_h=t(g["all_h"]))
+    assert np.array_equal(r2["codes"].numpy(), g["codes"])
+
+
+def test_bvrnn_float64_truth_agrees_on_codes(conf_var):
+    g = load_golden("g3_bvrnn_h1024_var")
+    sd = synth.bvrnn_state_dict(conf_var, seed=int(g["seed"]))
+    r = obv.encode(sd, t(g["y"]), t(g["bits"]), torch.zeros(2, 1024), dtype=torch.float64)
+    assert np.array_equal(r["codes"].float().numpy(), g["codes"])
+
+
+# ----------------------------------------------------------------- A8: BigVGAN
+def test_bigvgan_matches_reference(conf_var):
+    g = load_golden("g5_bigvgan")
+    sd = synth.generator_state_dict(conf_var, seed=int(g["seed"]))
+    T = g["mel"].shape[2]
+    for length in (8192, 8392, 10 ** 9):
+        w = obig.forward(sd, conf_var["vocoder_config"], t(g["mel"]), length)
+        ref = g[f"wav_{length}"]
+        assert w.shape == ref.shape and w.shape[2] == min(length, 256 * T + 294)
+        assert np.abs(w.numpy() - ref).max() < 2e-6
+    assert float(np.sqrt((g["wav_8192"] ** 2).mean())) > 0.05            # a non-trivial signal
+
+
+def test_bigvgan_stage_taps(conf_var):
+    g = load_golden("g5_bigvgan_taps")
+    sd = synth.generator_state_dict(conf_var, seed=int(g["seed"]))
+    taps = {}
+    w = obig.forward(sd, conf_var["vocoder_config"], t(g["mel"]), 10 ** 9, taps=taps)
+    assert np.abs(w.numpy() - g["wav"]).max() < 2e-6
+    T = g["mel"].shape[2]
+    for i, n in enumerate((8 * T + 8, 64 * T + 72, 128 * T + 146, 256 * T + 294)):
+        assert taps[f"up{i}"].shape[2] == n == g[f"up{i}"].shape[2]
+        assert np.abs(taps[f"up{i}"].numpy() - g[f"up{i}"]).max() < 1e-4
+        mean3 = (g[f"res{i}_0"] + g[f"res{i}_1"] + g[f"res{i}_2"]) / 3
+        assert np.abs(taps[f"stage{i}"].numpy() - mean3).max() < 1e-4
+    assert np.abs(taps["conv_pre"].numpy() - g["conv_pre"]).max() < 1e-5
+
+
+# ----------------------------------------------------------------- A2/A9: facade
+@pytest.mark.parametrize("tag", ["var", "fix"])
+def test_codec_end_to_end_matches_reference(tag, conf_var, conf_fix):
+    g = load_golden(f"g6_e2e_{tag}")
+    conf = conf_var if tag == "var" else conf_fix
+    seed = int(g["seed"])
+    oc = ocodec.OracleCodec(conf, synth.bvrnn_state_dict(conf, seed), synth.generator_state_dict(conf, seed + 1))
+    x = t(g["x"])
+    for br in ((3000, 1500, 6000) if tag == "var" else (3000,)):
+        codes = oc.encode(x, br)
+        assert np.array_equal(codes.numpy(), g[f"codes_{br}"]), br
+        wav = oc.decode(t(g[f"codes_{br}"]), x.shape[1])
+        assert wav.shape == g[f"wav_{br}"].shape
+        err = wav.numpy() - g[f"wav_{br}"]
+        assert np.sqrt((err ** 2).mean()) < 1e-5
+    if tag == "var":                     # 6000 bit/s saturates at 64 bits/frame; 1500 -> 17, 3000 -> 35
+        assert oc.bits_per_frame(6000) == 70.0
+        assert (g["codes_6000"] != 0.5).all()
+        assert (g["codes_3000"][:, :, 35:] == 0.5).all() and (g["codes_3000"][:, :, :35] != 0.5).all()
+        assert (g["codes_1500"][:, :, 17:] == 0.5).all()
+    else:
+        assert (g["codes_3000"] != 0.5).all()
+    un = oc.decode(t(g["codes_3000"]), 10 ** 9)
+    T = g["codes_3000"].shape[1]
+    assert un.shape[1] == 256 * T + 294 == g["wav_untrimmed_3000"].shape[1]
