@@ -1,0 +1,107 @@
+// Internal declarations shared by the gfx950 kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/bvcodec.h"
+
+namespace bvc {
+
+void set_error(const char *fmt, ...);
+
+#define BVC_HIP_TRY(expr)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            bvc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return BVC_EHIP;                                                           \
+        }                                                                              \
+    } while (0)
+
+// ------------------------------------------------------------------ skinny / recurrent GEMM (k_gemm.hip)
+// One K-segment of a (possibly concatenated) input:  acc[grp] += x[M,K] @ w[rows,K]^T
+struct GemmSeg {
+    const float *x;      // [M][ldx]
+    long long    ldx;
+    const float *w;      // [rows][ldw], row = gate*gate_rows + n
+    long long    ldw;
+    int          K;      // multiple of 16
+    int          grp;    // accumulator group (0: input part, 1: hidden part of the GRU)
+};
+
+enum GemmEpi {
+    EPI_LINEAR = 0,      // y = acc + bias
+    EPI_ELU = 1,         // y = elu(acc + bias)
+    EPI_CODE = 2,        // p = sigmoid(acc+bias); z = rint(p); masked by bits  (bvrnn.py:189-194)
+    EPI_MEL = 3,         // y = acc + bias (mel frame) ; y2 = (y - mean) / std  (bvrnn.py:202-204)
+    EPI_GRU = 4          // PyTorch GRU cell, 3 gates x 2 groups
+};
+
+struct GemmParams {
+    GemmSeg seg[3];
+    int     nseg;
+    int     M, N;              // N = outputs per gate (multiple of 16)
+    long long gate_rows;       // row distance between gates inside w (GRU: h_dim)
+    const float *bias0;        // group 0 bias [gates*N]
+    const float *bias1;        // group 1 bias (GRU only)
+    float  *y;   long long ldy;
+    float  *y2;  long long ldy2;     // optional second output
+    float  *y3;  long long ldy3;     // optional third output (CODE: prob dump)
+    const float *aux; long long ldaux;   // CODE: bits per frame (one per row); GRU: previous h [M][ldaux]
+    const float *mean; const float *stdv; // MEL epilogue
+    int     var_bit;
+};
+
+int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s);
+
+// batched GEMM over all frames: y = act(x @ w^T + bias), M large
+int launch_gemm_batched(const float *x, long long ldx, const float *w, long long ldw, const float *bias,
+                        int M, int N, int K, int act, float *y, long long ldy, hipStream_t s);
+// yn = (y - mean) / std over rows of length n (bvrnn.py:173)
+int launch_normalize_rows(const float *y, const float *mean, const float *stdv, long long rows, int n,
+                          float *out, hipStream_t s);
+int launch_fill(float *p, float v, long long n, hipStream_t s);
+int launch_copy_rows(const float *src, long long lds, float *dst, long long ldd, int rows, int n, hipStream_t s);
+
+// ------------------------------------------------------------------ front-end (k_frontend.hip)
+struct FrontendTables {          // device pointers
+    const float *window;         // [1024]
+    const float2 *tw1;           // [8][64]  W_512^(lane*k0)
+    const float2 *tw2;           // [8][8]   W_64^(n0*k1)
+    const float2 *tws;           // [513]    e^{-2 pi i k / 1024}
+    const int   *mel_start;      // [num_mels]
+    const int   *mel_len;        // [num_mels]
+    const int   *mel_off;        // [num_mels] offset into mel_w
+    const float *mel_w;          // packed non-zero weights
+    int num_mels;
+    int kmax;                    // highest bin with non-zero weight (+1)
+};
+int launch_stft_logmel(const FrontendTables &t, const float *wav, int B, long long L, long long T,
+                       int pad_left, float scale, float *mel, hipStream_t s);
+
+// ------------------------------------------------------------------ vocoder (k_vocoder.hip)
+struct ConvLayer {               // one causal conv as implicit GEMM on fp32 MFMA
+    int cin;                     // input channels (multiple of 4)
+    int cout;                    // real output columns
+    int ntiles;                  // ceil(cout/16)
+    int ks;                      // taps
+    int dil;
+    const float *wp;             // packed B fragments [ks][cin/4][ntiles][64]
+    const float *bias;           // [cout] (for ConvT: bias replicated per phase)
+    const float *act_a;          // exp(alpha) per input channel or nullptr (no input activation)
+    const float *act_ib;         // 1/(exp(beta)+1e-9)
+};
+enum ConvEpi { CE_STORE = 0, CE_RES = 1, CE_RES_ACC = 2, CE_RES_ACC_DIV = 3 };
+// in (B, Lin, cin) channels-last; out (B, Lout, cout).  Output row r reads input rows
+// r - (ks-1)*dil ... r  (rows outside [0,Lin) are zero).  res/acc have the layout of out.
+int conv_kernels_init();
+int launch_conv_mfma(const ConvLayer &c, const float *in, long long Lin, float *out, long long Lout,
+                     int B, int epi, const float *res, const float *acc, float divisor, hipStream_t s);
+// SnakeBeta -> causal conv C->1 (k taps) -> tanh -> / div -> first n_out samples
+int launch_conv_post(const float *in, long long Lin, int C, int ks, const float *w, const float *bias,
+                     const float *act_a, const float *act_ib, float div, float *wav, long long n_out,
+                     int B, hipStream_t s);
+
+}  // namespace bvc

@@ -1,0 +1,696 @@
+// C ABI of libbvcodec_hip.so (include/bvcodec.h): model creation (weight upload + re-layout into
+// MFMA fragment order), workspace carving and the per-call kernel schedules of the
+// BVRNNCodecModel encode/decode path.  Host-side only; the kernels are in k_*.hip.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "bvc_internal.h"
+
+namespace bvc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct Linear { const float *w = nullptr, *b = nullptr; int in = 0, out = 0; };
+
+struct AmpPair { ConvLayer c1, c2; };
+
+}  // namespace bvc
+
+using namespace bvc;
+
+struct bvc_model {
+    bvc_config cfg;
+    std::vector<void *> allocs;
+    // front-end
+    FrontendTables fe;
+    // BVRNN
+    const float *mean_mel = nullptr, *std_mel = nullptr;
+    Linear phi_x[3], phi_z[3], enc[3], dec[4];
+    const float *w_ih = nullptr, *w_hh = nullptr, *b_ih = nullptr, *b_hh = nullptr;
+    // vocoder
+    ConvLayer conv_pre;
+    std::vector<ConvLayer> ups;                       // n_up
+    std::vector<std::vector<std::vector<AmpPair>>> amp;   // [stage][kernel][dilation]
+    std::vector<int> stage_ch;                        // channels after each upsampler
+    const float *post_a = nullptr, *post_ib = nullptr, *post_w = nullptr, *post_b = nullptr;
+    int post_c = 0, post_ks = 7;
+
+    ~bvc_model() {
+        for (void *p : allocs) (void)hipFree(p);
+    }
+};
+
+namespace {
+
+typedef std::map<std::string, const bvc_tensor *> TensorMap;
+
+template <typename T>
+int upload(bvc_model *m, const std::vector<T> &host, const T **dev) {
+    void *d = nullptr;
+    const size_t bytes = host.size() * sizeof(T);
+    BVC_HIP_TRY(hipMalloc(&d, bytes ? bytes : 16));
+    m->allocs.push_back(d);
+    if (bytes) BVC_HIP_TRY(hipMemcpy(d, host.data(), bytes, hipMemcpyHostToDevice));
+    *dev = static_cast<const T *>(d);
+    return BVC_OK;
+}
+
+int upload_raw(bvc_model *m, const float *h, int64_t n, const float **dev) {
+    void *d = nullptr;
+    BVC_HIP_TRY(hipMalloc(&d, (size_t)n * sizeof(float)));
+    m->allocs.push_back(d);
+    BVC_HIP_TRY(hipMemcpy(d, h, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    *dev = static_cast<const float *>(d);
+    return BVC_OK;
+}
+
+const bvc_tensor *find(const TensorMap &tm, const std::string &name, int64_t numel) {
+    auto it = tm.find(name);
+    if (it == tm.end()) { set_error("missing tensor '%s'", name.c_str()); return nullptr; }
+    if (it->second->numel != numel || !it->second->h_data) {
+        set_error("tensor '%s' has %lld elements, expected %lld", name.c_str(),
+                  (long long)it->second->numel, (long long)numel);
+        return nullptr;
+    }
+    return it->second;
+}
+
+int load_linear(bvc_model *m, const TensorMap &tm, const std::string &name, int in, int out, Linear *l) {
+    const bvc_tensor *w = find(tm, name + ".weight", (int64_t)in * out);
+    if (!w) return BVC_EMISSING;
+    const bvc_tensor *b = find(tm, name + ".bias", out);
+    if (!b) return BVC_EMISSING;
+    l->in = in; l->out = out;
+    int rc;
+    if ((rc = upload_raw(m, w->h_data, w->numel, &l->w))) return rc;
+    return upload_raw(m, b->h_data, b->numel, &l->b);
+}
+
+// Conv1d weight W[cout][cin][ks] -> MFMA B fragments [ks][cin/4][ntiles][64]
+std::vector<float> pack_conv(const float *W, int cout, int cin, int ks) {
+    const int c4 = cin / 4, ntiles = (cout + 15) / 16;
+    std::vector<float> p((size_t)ks * c4 * ntiles * 64, 0.0f);
+    for (int j = 0; j < ks; ++j)
+        for (int cg = 0; cg < c4; ++cg)
+            for (int nt = 0; nt < ntiles; ++nt)
+                for (int l = 0; l < 64; ++l) {
+                    const int co = nt * 16 + (l & 15), ci = cg * 4 + (l >> 4);
+                    if (co < cout)
+                        p[(((size_t)j * c4 + cg) * ntiles + nt) * 64 + l] = W[((size_t)co * cin + ci) * ks + j];
+                }
+    return p;
+}
+
+// ConvTranspose1d weight W[cin][cout][2u] -> 2-tap conv with u*cout columns (polyphase form)
+std::vector<float> convt_as_conv(const float *W, int cin, int cout, int u) {
+    const int k = 2 * u, ncol = u * cout;
+    std::vector<float> v((size_t)ncol * cin * 2);
+    for (int p = 0; p < u; ++p)
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci) {
+                const size_t n = (size_t)p * cout + co;
+                v[(n * cin + ci) * 2 + 0] = W[((size_t)ci * cout + co) * k + p + u];   // tap on in[q-1]
+                v[(n * cin + ci) * 2 + 1] = W[((size_t)ci * cout + co) * k + p];       // tap on in[q]
+            }
+    return v;
+}
+
+int make_conv(bvc_model *m, const float *W, const float *bias, int nbias_rep, int cout, int cin, int ks, int dil,
+              const float *alpha, const float *beta, ConvLayer *c) {
+    c->cin = cin; c->cout = cout; c->ntiles = (cout + 15) / 16; c->ks = ks; c->dil = dil;
+    c->act_a = c->act_ib = nullptr;
+    int rc;
+    std::vector<float> wp = pack_conv(W, cout, cin, ks);
+    if ((rc = upload(m, wp, &c->wp))) return rc;
+    std::vector<float> b((size_t)cout);
+    const int per = cout / nbias_rep;
+    for (int i = 0; i < cout; ++i) b[i] = bias[i % per];
+    if ((rc = upload(m, b, &c->bias))) return rc;
+    if (alpha) {
+        std::vector<float> a(cin), ib(cin);
+        for (int i = 0; i < cin; ++i) {
+            a[i] = (float)std::exp((double)alpha[i]);                      // torch.exp(alpha)
+            const float eb = (float)std::exp((double)beta[i]);
+            ib[i] = 1.0f / (eb + 0.000000001f);                            // activations.py:116
+        }
+        if ((rc = upload(m, a, &c->act_a))) return rc;
+        if ((rc = upload(m, ib, &c->act_ib))) return rc;
+    }
+    return BVC_OK;
+}
+
+int build_frontend(bvc_model *m, const TensorMap &tm) {
+    const bvc_config &c = m->cfg;
+    const int nfft = c.n_fft, nbins = nfft / 2 + 1;
+    const double PI = 3.14159265358979323846;
+    std::vector<float> win(nfft);
+    auto itw = tm.find("hann_window");
+    if (itw != tm.end() && itw->second->numel == nfft) {
+        memcpy(win.data(), itw->second->h_data, sizeof(float) * nfft);
+    } else {
+        for (int n = 0; n < nfft; ++n) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * n / nfft));
+    }
+    std::vector<float2> tw1(8 * 64), tw2(64), tws(nbins);
+    for (int k = 0; k < 8; ++k)
+        for (int l = 0; l < 64; ++l) {
+            const double a = -2.0 * PI * (double)(l * k) / 512.0;
+            tw1[k * 64 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k = 0; k < 8; ++k)
+        for (int n = 0; n < 8; ++n) {
+            const double a = -2.0 * PI * (double)(n * k) / 64.0;
+            tw2[k * 8 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k = 0; k < nbins; ++k) {
+        const double a = -2.0 * PI * (double)k / 1024.0;
+        tws[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    const bvc_tensor *mb = find(tm, "mel_basis", (int64_t)c.num_mels * nbins);
+    if (!mb) return BVC_EMISSING;
+    std::vector<int> st(c.num_mels), ln(c.num_mels), off(c.num_mels);
+    std::vector<float> w;
+    int kmax = 1;
+    for (int j = 0; j < c.num_mels; ++j) {
+        const float *row = mb->h_data + (size_t)j * nbins;
+        int lo = -1, hi = -1;
+        for (int k = 0; k < nbins; ++k)
+            if (row[k] != 0.0f) { if (lo < 0) lo = k; hi = k; }
+        if (lo < 0) { lo = 0; hi = -1; }
+        st[j] = lo; ln[j] = hi - lo + 1; off[j] = (int)w.size();
+        for (int k = lo; k <= hi; ++k) w.push_back(row[k]);
+        if (hi + 1 > kmax) kmax = hi + 1;
+    }
+    FrontendTables &t = m->fe;
+    int rc;
+    if ((rc = upload(m, win, &t.window))) return rc;
+    if ((rc = upload(m, tw1, &t.tw1))) return rc;
+    if ((rc = upload(m, tw2, &t.tw2))) return rc;
+    if ((rc = upload(m, tws, &t.tws))) return rc;
+    if ((rc = upload(m, st, &t.mel_start))) return rc;
+    if ((rc = upload(m, ln, &t.mel_len))) return rc;
+    if ((rc = upload(m, off, &t.mel_off))) return rc;
+    if ((rc = upload(m, w, &t.mel_w))) return rc;
+    t.num_mels = c.num_mels;
+    t.kmax = kmax;
+    return BVC_OK;
+}
+
+int build_bvrnn(bvc_model *m, const TensorMap &tm) {
+    const int X = m->cfg.num_mels, H = m->cfg.h_dim, Z = m->cfg.z_dim;
+    int rc;
+    const bvc_tensor *t;
+    if (!(t = find(tm, "mean_mel", X))) return BVC_EMISSING;
+    if ((rc = upload_raw(m, t->h_data, X, &m->mean_mel))) return rc;
+    if (!(t = find(tm, "std_mel", X))) return BVC_EMISSING;
+    if ((rc = upload_raw(m, t->h_data, X, &m->std_mel))) return rc;
+    const int px_in[3] = {X, H, H}, pz_in[3] = {Z, H, H}, en_in[3] = {2 * H, H, H}, en_out[3] = {H, H, Z};
+    const int de_in[4] = {2 * H, H, H, H}, de_out[4] = {H, H, H, X};
+    for (int i = 0; i < 3; ++i) {
+        const std::string idx = std::to_string(2 * i);
+        if ((rc = load_linear(m, tm, "phi_x." + idx, px_in[i], H, &m->phi_x[i]))) return rc;
+        if ((rc = load_linear(m, tm, "phi_z." + idx, pz_in[i], H, &m->phi_z[i]))) return rc;
+        if ((rc = load_linear(m, tm, "enc." + idx, en_in[i], en_out[i], &m->enc[i]))) return rc;
+    }
+    for (int i = 0; i < 4; ++i)
+        if ((rc = load_linear(m, tm, "dec." + std::to_string(2 * i), de_in[i], de_out[i], &m->dec[i]))) return rc;
+    if (!(t = find(tm, "rnn.weight_ih_l0", (int64_t)3 * H * 2 * H))) return BVC_EMISSING;
+    if ((rc = upload_raw(m, t->h_data, t->numel, &m->w_ih))) return rc;
+    if (!(t = find(tm, "rnn.weight_hh_l0", (int64_t)3 * H * H))) return BVC_EMISSING;
+    if ((rc = upload_raw(m, t->h_data, t->numel, &m->w_hh))) return rc;
+    if (!(t = find(tm, "rnn.bias_ih_l0", 3 * H))) return BVC_EMISSING;
+    if ((rc = upload_raw(m, t->h_data, t->numel, &m->b_ih))) return rc;
+    if (!(t = find(tm, "rnn.bias_hh_l0", 3 * H))) return BVC_EMISSING;
+    if ((rc = upload_raw(m, t->h_data, t->numel, &m->b_hh))) return rc;
+    return BVC_OK;
+}
+
+int build_vocoder(bvc_model *m, const TensorMap &tm) {
+    const bvc_config &c = m->cfg;
+    int rc;
+    const bvc_tensor *w, *b;
+    const int c0 = c.upsample_initial_channel;
+    if (!(w = find(tm, "conv_pre.weight", (int64_t)c0 * c.num_mels * 7))) return BVC_EMISSING;
+    if (!(b = find(tm, "conv_pre.bias", c0))) return BVC_EMISSING;
+    if ((rc = make_conv(m, w->h_data, b->h_data, 1, c0, c.num_mels, 7, 1, nullptr, nullptr, &m->conv_pre))) return rc;
+    int ch = c0;
+    m->ups.resize(c.n_up);
+    m->amp.resize(c.n_up);
+    m->stage_ch.resize(c.n_up);
+    for (int i = 0; i < c.n_up; ++i) {
+        const int u = c.up_rates[i], cin = ch, cout = ch / 2;
+        const std::string nm = "ups." + std::to_string(i) + ".1";
+        if (!(w = find(tm, nm + ".weight", (int64_t)cin * cout * 2 * u))) return BVC_EMISSING;
+        if (!(b = find(tm, nm + ".bias", cout))) return BVC_EMISSING;
+        std::vector<float> wv = convt_as_conv(w->h_data, cin, cout, u);
+        if ((rc = make_conv(m, wv.data(), b->h_data, u, u * cout, cin, 2, 1, nullptr, nullptr, &m->ups[i]))) return rc;
+        ch = cout;
+        m->stage_ch[i] = ch;
+        m->amp[i].resize(c.n_resk);
+        for (int j = 0; j < c.n_resk; ++j) {
+            const int ks = c.res_kernels[j];
+            const std::string pre = "resblocks." + std::to_string(i * c.n_resk + j);
+            m->amp[i][j].resize(3);
+            for (int d = 0; d < 3; ++d) {
+                const bvc_tensor *a1, *b1, *a2, *b2, *w1, *bb1, *w2, *bb2;
+                const std::string ds = std::to_string(d);
+                if (!(a1 = find(tm, pre + ".activations." + std::to_string(2 * d) + ".alpha", ch))) return BVC_EMISSING;
+                if (!(b1 = find(tm, pre + ".activations." + std::to_string(2 * d) + ".beta", ch))) return BVC_EMISSING;
+                if (!(a2 = find(tm, pre + ".activations." + std::to_string(2 * d + 1) + ".alpha", ch))) return BVC_EMISSING;
+                if (!(b2 = find(tm, pre + ".activations." + std::to_string(2 * d + 1) + ".beta", ch))) return BVC_EMISSING;
+                if (!(w1 = find(tm, pre + ".convs1." + ds + ".weight", (int64_t)ch * ch * ks))) return BVC_EMISSING;
+                if (!(bb1 = find(tm, pre + ".convs1." + ds + ".bias", ch))) return BVC_EMISSING;
+                if (!(w2 = find(tm, pre + ".convs2." + ds + ".weight", (int64_t)ch * ch * ks))) return BVC_EMISSING;
+                if (!(bb2 = find(tm, pre + ".convs2." + ds + ".bias", ch))) return BVC_EMISSING;
+                AmpPair &ap = m->amp[i][j][d];
+                if ((rc = make_conv(m, w1->h_data, bb1->h_data, 1, ch, ch, ks, c.res_dilations[j][d], a1->h_data,
+                                    b1->h_data, &ap.c1))) return rc;
+                if ((rc = make_conv(m, w2->h_data, bb2->h_data, 1, ch, ch, ks, 1, a2->h_data, b2->h_data, &ap.c2)))
+                    return rc;
+            }
+        }
+    }
+    m->post_c = ch;
+    const bvc_tensor *pa, *pb;
+    if (!(pa = find(tm, "activation_post.alpha", ch))) return BVC_EMISSING;
+    if (!(pb = find(tm, "activation_post.beta", ch))) return BVC_EMISSING;
+    std::vector<float> a(ch), ib(ch);
+    for (int i = 0; i < ch; ++i) {
+        a[i] = (float)std::exp((double)pa->h_data[i]);
+        ib[i] = 1.0f / ((float)std::exp((double)pb->h_data[i]) + 0.000000001f);
+    }
+    if ((rc = upload(m, a, &m->post_a))) return rc;
+    if ((rc = upload(m, ib, &m->post_ib))) return rc;
+    if (!(w = find(tm, "conv_post.weight", (int64_t)ch * 7))) return BVC_EMISSING;
+    if (!(b = find(tm, "conv_post.bias", 1))) return BVC_EMISSING;
+    if ((rc = upload_raw(m, w->h_data, w->numel, &m->post_w))) return rc;
+    if ((rc = upload_raw(m, b->h_data, 1, &m->post_b))) return rc;
+    return BVC_OK;
+}
+
+int check_config(const bvc_config *c) {
+    if (!c) { set_error("null config"); return BVC_EINVAL; }
+    if (c->n_fft != 1024 || c->hop != 256) { set_error("front-end kernel needs n_fft=1024, hop=256"); return BVC_EINVAL; }
+    if (c->pad_left < 0 || c->pad_left > c->n_fft - c->hop) { set_error("pad_left out of range"); return BVC_EINVAL; }
+    if (c->num_mels % 16 || c->h_dim % 16 || c->z_dim % 16 || c->num_mels > 128) {
+        set_error("num_mels/h_dim/z_dim must be multiples of 16 (num_mels <= 128)"); return BVC_EINVAL; }
+    if (c->n_up < 1 || c->n_up > 8 || c->n_resk < 1 || c->n_resk > 4) { set_error("bad n_up / n_resk"); return BVC_EINVAL; }
+    int ch = c->upsample_initial_channel;
+    if (ch != 128 && ch != 64 && ch != 32 && ch != 16) { set_error("unsupported upsample_initial_channel %d", ch); return BVC_EINVAL; }
+    for (int i = 0; i < c->n_up; ++i) {
+        if (c->up_kernels[i] != 2 * c->up_rates[i]) { set_error("upsample kernel must be 2*rate"); return BVC_EINVAL; }
+        ch /= 2;
+        if (ch < 8) { set_error("too many upsampling stages for %d initial channels", c->upsample_initial_channel); return BVC_EINVAL; }
+    }
+    if (ch != 8) { set_error("final channel count must be 8 (got %d)", ch); return BVC_EINVAL; }
+    if (c->num_mels != 80) { set_error("conv_pre kernel is built for num_mels=80"); return BVC_EINVAL; }
+    return BVC_OK;
+}
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// ---- workspace layout ---------------------------------------------------------------------------
+struct Workspace {
+    // encode
+    float *yn, *pxA, *pxB;
+    float *step[16];            // per-step [B, max(H, ...)] scratch vectors
+    float *hA, *hB;
+    float *mel, *bits;          // facade-level buffers
+    // vocoder
+    float *y0, *X, *P, *Q, *U, *XS;
+    size_t total;
+};
+
+int64_t stage_len(const bvc_model *m, int64_t T, int stage) {    // length after upsampler `stage`
+    int64_t L = T;
+    for (int i = 0; i <= stage; ++i) L = (L + 1) * m->cfg.up_rates[i];
+    return L;
+}
+
+void carve(const bvc_model *m, int B, int64_t T, char *base, Workspace *w) {
+    const bvc_config &c = m->cfg;
+    size_t off = 0;
+    auto take = [&](size_t nfloats) {
+        float *p = reinterpret_cast<float *>(base + off);
+        off += align_up(nfloats * sizeof(float));
+        return p;
+    };
+    const size_t BT = (size_t)B * (size_t)T;
+    const int H = c.h_dim;
+    const int vmax = H > c.num_mels ? H : c.num_mels;
+    w->yn = take(BT * c.num_mels);
+    w->pxA = take(BT * H);
+    w->pxB = take(BT * H);
+    for (int i = 0; i < 16; ++i) w->step[i] = take((size_t)B * vmax);
+    w->hA = take((size_t)B * H);
+    w->hB = take((size_t)B * H);
+    w->mel = take(BT * c.num_mels);
+    w->bits = take(BT);
+    size_t maxel = 0;
+    for (int i = 0; i < c.n_up; ++i) {
+        const size_t e = (size_t)stage_len(m, T, i) * m->stage_ch[i];
+        if (e > maxel) maxel = e;
+    }
+    w->y0 = take((size_t)B * T * c.upsample_initial_channel);
+    w->X = take((size_t)B * maxel);
+    w->P = take((size_t)B * maxel);
+    w->Q = take((size_t)B * maxel);
+    w->U = take((size_t)B * maxel);
+    w->XS = take((size_t)B * maxel);
+    w->total = off;
+}
+
+int check_ws(const bvc_model *m, int B, int64_t T, void *d_ws, size_t ws_bytes, Workspace *w) {
+    if (!m) { set_error("null model"); return BVC_EINVAL; }
+    if (B <= 0 || T <= 0) { set_error("B and T must be positive (B=%d, T=%lld)", B, (long long)T); return BVC_EINVAL; }
+    carve(m, B, T, static_cast<char *>(d_ws), w);
+    if (!d_ws || ws_bytes < w->total) {
+        set_error("workspace too small: %zu bytes given, %zu needed", ws_bytes, w->total);
+        return BVC_ENOMEM;
+    }
+    return BVC_OK;
+}
+
+GemmParams lin_params(const Linear &l, const float *x, long long ldx, int M, float *y, long long ldy) {
+    GemmParams p;
+    memset(&p, 0, sizeof(p));
+    p.nseg = 1;
+    p.seg[0] = {x, ldx, l.w, (long long)l.in, l.in, 0};
+    p.M = M; p.N = l.out; p.gate_rows = 0;
+    p.bias0 = l.b;
+    p.y = y; p.ldy = ldy;
+    return p;
+}
+
+// linear over the concatenation [x1 | x2] (torch.cat at bvrnn.py:189,202)
+GemmParams lin2_params(const Linear &l, const float *x1, long long ld1, int K1, const float *x2, long long ld2,
+                       int K2, int M, float *y, long long ldy) {
+    GemmParams p = lin_params(l, x1, ld1, M, y, ldy);
+    p.nseg = 2;
+    p.seg[0] = {x1, ld1, l.w, (long long)l.in, K1, 0};
+    p.seg[1] = {x2, ld2, l.w + K1, (long long)l.in, K2, 0};
+    return p;
+}
+
+// phi_z -> dec -> phi_x(normalised dec) -> GRU : the part shared by encode and decode steps
+// (bvrnn.py:198-206 / 223-227).  z = codes of frame t (row stride ldz).
+int step_tail(const bvc_model *m, const Workspace &w, int B, const float *z, long long ldz, const float *h_cur,
+              float *h_next, float *mel_out, long long ldmel, float *h_copy, long long ldhc, hipStream_t s) {
+    const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
+    int rc;
+    float *pz1 = w.step[2], *pz2 = w.step[3], *pz3 = w.step[4];
+    float *d1 = w.step[5], *d2 = w.step[6], *d3 = w.step[7], *dn = w.step[8];
+    float *g1 = w.step[9], *g2 = w.step[10], *g3 = w.step[11];
+    if ((rc = launch_gemm_skinny(lin_params(m->phi_z[0], z, ldz, B, pz1, H), EPI_ELU, s))) return rc;
+    if ((rc = launch_gemm_skinny(lin_params(m->phi_z[1], pz1, H, B, pz2, H), EPI_ELU, s))) return rc;
+    if ((rc = launch_gemm_skinny(lin_params(m->phi_z[2], pz2, H, B, pz3, H), EPI_ELU, s))) return rc;
+    if ((rc = launch_gemm_skinny(lin2_params(m->dec[0], pz3, H, H, h_cur, H, H, B, d1, H), EPI_ELU, s))) return rc;
+    if ((rc = launch_gemm_skinny(lin_params(m->dec[1], d1, H, B, d2, H), EPI_ELU, s))) return rc;
+    if ((rc = launch_gemm_skinny(lin_params(m->dec[2], d2, H, B, d3, H), EPI_ELU, s))) return rc;
+    {
+        GemmParams p = lin_params(m->dec[3], d3, H, B, mel_out, ldmel);
+        p.y2 = dn; p.ldy2 = X; p.mean = m->mean_mel; p.stdv = m->std_mel;
+        if ((rc = launch_gemm_skinny(p, EPI_MEL, s))) return rc;
+    }
+    if ((rc = launch_gemm_skinny(lin_params(m->phi_x[0], dn, X, B, g1, H), EPI_ELU, s))) return rc;
+    if ((rc = launch_gemm_skinny(lin_params(m->phi_x[1], g1, H, B, g2, H), EPI_ELU, s))) return rc;
+    if ((rc = launch_gemm_skinny(lin_params(m->phi_x[2], g2, H, B, g3, H), EPI_ELU, s))) return rc;
+    {
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.nseg = 3;
+        p.seg[0] = {g3, (long long)H, m->w_ih, 2LL * H, H, 0};            // cat([phi_x_gen, phi_z]) bvrnn.py:206
+        p.seg[1] = {pz3, (long long)H, m->w_ih + H, 2LL * H, H, 0};
+        p.seg[2] = {h_cur, (long long)H, m->w_hh, (long long)H, H, 1};
+        p.M = B; p.N = H; p.gate_rows = H;
+        p.bias0 = m->b_ih; p.bias1 = m->b_hh;
+        p.y = h_next; p.ldy = H;
+        p.y2 = h_copy; p.ldy2 = ldhc;
+        p.aux = h_cur; p.ldaux = H;
+        if ((rc = launch_gemm_skinny(p, EPI_GRU, s))) return rc;
+    }
+    (void)Z;
+    return BVC_OK;
+}
+
+int run_encode(const bvc_model *m, const Workspace &w, const float *d_mel, const float *d_bits, const float *d_h0,
+               int B, int64_t T, float *d_codes, float *d_all_h, float *d_hT, float *d_prob, hipStream_t s) {
+    const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
+    const long long BT = (long long)B * T;
+    int rc;
+    if (m->cfg.var_bit && !d_bits) { set_error("bits per frame required when var_bit=1"); return BVC_EINVAL; }
+    // y = (y - mean) / std ; phi_x over all frames (bvrnn.py:173-178)
+    if ((rc = launch_normalize_rows(d_mel, m->mean_mel, m->std_mel, BT, X, w.yn, s))) return rc;
+    if ((rc = launch_gemm_batched(w.yn, X, m->phi_x[0].w, X, m->phi_x[0].b, (int)BT, H, X, 1, w.pxA, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxA, H, m->phi_x[1].w, H, m->phi_x[1].b, (int)BT, H, H, 1, w.pxB, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxB, H, m->phi_x[2].w, H, m->phi_x[2].b, (int)BT, H, H, 1, w.pxA, H, s))) return rc;
+    float *h_cur = w.hA, *h_next = w.hB;
+    if (d_h0) { if ((rc = launch_copy_rows(d_h0, H, h_cur, H, B, H, s))) return rc; }
+    else      { if ((rc = launch_fill(h_cur, 0.0f, (long long)B * H, s))) return rc; }
+    if (d_all_h && (rc = launch_copy_rows(h_cur, H, d_all_h, (long long)T * H, B, H, s))) return rc;
+    float *e1 = w.step[0], *e2 = w.step[1];
+    for (int64_t t = 0; t < T; ++t) {
+        // enc(cat[phi_x_t, h]) -> sigmoid -> round -> bit mask  (bvrnn.py:187-194)
+        if ((rc = launch_gemm_skinny(lin2_params(m->enc[0], w.pxA + t * H, (long long)T * H, H, h_cur, H, H, B, e1, H),
+                                     EPI_ELU, s))) return rc;
+        if ((rc = launch_gemm_skinny(lin_params(m->enc[1], e1, H, B, e2, H), EPI_ELU, s))) return rc;
+        {
+            GemmParams p = lin_params(m->enc[2], e2, H, B, d_codes + t * Z, (long long)T * Z);
+            p.var_bit = m->cfg.var_bit;
+            p.aux = d_bits ? d_bits + t : nullptr; p.ldaux = T;
+            if (d_prob) { p.y3 = d_prob + t * Z; p.ldy3 = (long long)T * Z; }
+            if ((rc = launch_gemm_skinny(p, EPI_CODE, s))) return rc;
+        }
+        float *hc = (d_all_h && t + 1 < T) ? d_all_h + (t + 1) * H : nullptr;
+        if ((rc = step_tail(m, w, B, d_codes + t * Z, (long long)T * Z, h_cur, h_next, nullptr, 0, hc,
+                            (long long)T * H, s))) return rc;
+        float *tmp = h_cur; h_cur = h_next; h_next = tmp;
+    }
+    if (d_hT && (rc = launch_copy_rows(h_cur, H, d_hT, H, B, H, s))) return rc;
+    return BVC_OK;
+}
+
+int run_decode(const bvc_model *m, const Workspace &w, const float *d_codes, const float *d_h0, int B, int64_t T,
+               float *d_mel, float *d_hT, hipStream_t s) {
+    const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
+    int rc;
+    float *h_cur = w.hA, *h_next = w.hB;
+    if (d_h0) { if ((rc = launch_copy_rows(d_h0, H, h_cur, H, B, H, s))) return rc; }
+    else      { if ((rc = launch_fill(h_cur, 0.0f, (long long)B * H, s))) return rc; }
+    for (int64_t t = 0; t < T; ++t) {
+        if ((rc = step_tail(m, w, B, d_codes + t * Z, (long long)T * Z, h_cur, h_next, d_mel + t * X,
+                            (long long)T * X, nullptr, 0, s))) return rc;
+        float *tmp = h_cur; h_cur = h_next; h_next = tmp;
+    }
+    if (d_hT && (rc = launch_copy_rows(h_cur, H, d_hT, H, B, H, s))) return rc;
+    return BVC_OK;
+}
+
+// Runs the generator; stop_after: -1 = everything, otherwise the tap index of bvc_test_vocoder_tap.
+int run_vocoder(const bvc_model *m, const Workspace &w, const float *d_mel, int B, int64_t T, int64_t length,
+                float div, float *d_wav, int stop_after, const float **tap, int64_t *tap_len, int *tap_ch,
+                hipStream_t s) {
+    const bvc_config &c = m->cfg;
+    int rc;
+    // pad[6,0] + conv_pre (models.py:212-213); input is already time-major (B,T,80)
+    if ((rc = launch_conv_mfma(m->conv_pre, d_mel, T, w.y0, T, B, CE_STORE, nullptr, nullptr, 1.0f, s))) return rc;
+    if (stop_after == 0) { *tap = w.y0; *tap_len = T; *tap_ch = c.upsample_initial_channel; return BVC_OK; }
+    const float *cur_in = w.y0;
+    int64_t Lin = T;
+    for (int i = 0; i < c.n_up; ++i) {
+        const int C = m->stage_ch[i];
+        const int64_t L = (Lin + 1) * c.up_rates[i];
+        // ConvTranspose1d as a 2-tap conv with u*C columns over Lin+1 rows (models.py:216-217)
+        if ((rc = launch_conv_mfma(m->ups[i], cur_in, Lin, w.X, Lin + 1, B, CE_STORE, nullptr, nullptr, 1.0f, s))) return rc;
+        if (stop_after == 1 + 2 * i) { *tap = w.X; *tap_len = L; *tap_ch = C; return BVC_OK; }
+        for (int j = 0; j < c.n_resk; ++j) {                            // three parallel AMP blocks
+            const float *cur = w.X;
+            for (int d = 0; d < 3; ++d) {
+                const AmpPair &ap = m->amp[i][j][d];
+                if ((rc = launch_conv_mfma(ap.c1, cur, L, w.U, L, B, CE_STORE, nullptr, nullptr, 1.0f, s))) return rc;
+                float *dst;
+                int epi = CE_RES;
+                if (d < 2) dst = (d == 0) ? w.P : w.Q;
+                else {
+                    dst = w.XS;
+                    epi = (j == 0) ? CE_RES : (j + 1 < c.n_resk ? CE_RES_ACC : CE_RES_ACC_DIV);
+                    if (c.n_resk == 1) epi = CE_RES;
+                }
+                if ((rc = launch_conv_mfma(ap.c2, w.U, L, dst, L, B, epi, cur, w.XS, (float)c.n_resk, s))) return rc;
+                cur = dst;
+            }
+        }
+        if (stop_after == 2 + 2 * i) { *tap = w.XS; *tap_len = L; *tap_ch = C; return BVC_OK; }
+        cur_in = w.XS;
+        Lin = L;
+    }
+    const int64_t n_out = length < Lin ? length : Lin;
+    return launch_conv_post(cur_in, Lin, m->post_c, m->post_ks, m->post_w, m->post_b, m->post_a, m->post_ib, div,
+                            d_wav, n_out, B, s);
+}
+
+__global__ void tap_copy_kernel(const float *src, float *dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int bvc_abi_version(void) { return BVC_ABI_VERSION; }
+const char *bvc_last_error(void) { return g_err; }
+
+int bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t n_tensors, bvc_model **out) {
+    if (!out) { set_error("null out pointer"); return BVC_EINVAL; }
+    *out = nullptr;
+    int rc = check_config(cfg);
+    if (rc) return rc;
+    if (!tensors || n_tensors <= 0) { set_error("no tensors given"); return BVC_EINVAL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device visible: the gfx950 kernels cannot run (there is no CPU fallback)");
+        return BVC_ENODEVICE;
+    }
+    TensorMap tm;
+    for (int i = 0; i < n_tensors; ++i)
+        if (tensors[i].name) tm[tensors[i].name] = &tensors[i];
+    std::unique_ptr<bvc_model> m(new bvc_model());
+    m->cfg = *cfg;
+    if ((rc = conv_kernels_init())) return rc;
+    if ((rc = build_frontend(m.get(), tm))) return rc;
+    if ((rc = build_bvrnn(m.get(), tm))) return rc;
+    if ((rc = build_vocoder(m.get(), tm))) return rc;
+    BVC_HIP_TRY(hipDeviceSynchronize());
+    *out = m.release();
+    return BVC_OK;
+}
+
+void bvc_model_destroy(bvc_model *m) { delete m; }
+
+int64_t bvc_num_frames(const bvc_model *m, int64_t L) {
+    if (!m) return BVC_EINVAL;
+    const bvc_config &c = m->cfg;
+    const int64_t pr = c.n_fft - c.pad_left - c.hop;
+    if (L <= c.pad_left || L <= pr) return BVC_EINVAL;       // reflect padding needs pad < L
+    return (L + c.pad_left + pr - c.n_fft) / c.hop + 1;
+}
+
+int64_t bvc_vocoder_length(const bvc_model *m, int64_t T) {
+    if (!m || T <= 0) return BVC_EINVAL;
+    return stage_len(m, T, m->cfg.n_up - 1);
+}
+
+size_t bvc_workspace_bytes(const bvc_model *m, int32_t B, int64_t T) {
+    if (!m || B <= 0 || T <= 0) return 0;
+    Workspace w;
+    carve(m, B, T, nullptr, &w);
+    return w.total;
+}
+
+int bvc_stft_logmel(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, float scale, float *d_mel,
+                    void *stream) {
+    if (!m || !d_wav || !d_mel) { set_error("null argument"); return BVC_EINVAL; }
+    const int64_t T = bvc_num_frames(m, L);
+    if (B <= 0 || T <= 0) { set_error("input too short for reflect padding (L=%lld)", (long long)L); return BVC_EINVAL; }
+    return launch_stft_logmel(m->fe, d_wav, B, L, T, m->cfg.pad_left, scale, d_mel, (hipStream_t)stream);
+}
+
+int bvc_bvrnn_encode(const bvc_model *m, const float *d_mel, const float *d_bits, const float *d_h0, int32_t B,
+                     int64_t T, float *d_codes, float *d_all_h, float *d_hT, float *d_prob, void *d_ws,
+                     size_t ws_bytes, void *stream) {
+    Workspace w;
+    int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
+    if (rc) return rc;
+    if (!d_mel || !d_codes) { set_error("null argument"); return BVC_EINVAL; }
+    return run_encode(m, w, d_mel, d_bits, d_h0, B, T, d_codes, d_all_h, d_hT, d_prob, (hipStream_t)stream);
+}
+
+int bvc_bvrnn_decode(const bvc_model *m, const float *d_codes, const float *d_h0, int32_t B, int64_t T, float *d_mel,
+                     float *d_hT, void *d_ws, size_t ws_bytes, void *stream) {
+    Workspace w;
+    int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
+    if (rc) return rc;
+    if (!d_codes || !d_mel) { set_error("null argument"); return BVC_EINVAL; }
+    return run_decode(m, w, d_codes, d_h0, B, T, d_mel, d_hT, (hipStream_t)stream);
+}
+
+int bvc_bigvgan(const bvc_model *m, const float *d_mel, int32_t B, int64_t T, int64_t length, float out_scale_div,
+                float *d_wav, void *d_ws, size_t ws_bytes, void *stream) {
+    Workspace w;
+    int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
+    if (rc) return rc;
+    if (!d_mel || !d_wav || length <= 0) { set_error("null argument or non-positive length"); return BVC_EINVAL; }
+    return run_vocoder(m, w, d_mel, B, T, length, out_scale_div, d_wav, -1, nullptr, nullptr, nullptr,
+                       (hipStream_t)stream);
+}
+
+int bvc_encode(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, float scale, float bits_per_frame,
+               float *d_codes, void *d_ws, size_t ws_bytes, void *stream) {
+    if (!m) { set_error("null model"); return BVC_EINVAL; }
+    const int64_t T = bvc_num_frames(m, L);
+    if (T <= 0) { set_error("input too short for reflect padding (L=%lld)", (long long)L); return BVC_EINVAL; }
+    Workspace w;
+    int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
+    if (rc) return rc;
+    if (!d_wav || !d_codes) { set_error("null argument"); return BVC_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = launch_stft_logmel(m->fe, d_wav, B, L, T, m->cfg.pad_left, scale, w.mel, s))) return rc;
+    if ((rc = launch_fill(w.bits, bits_per_frame, (long long)B * T, s))) return rc;
+    return run_encode(m, w, w.mel, w.bits, nullptr, B, T, d_codes, nullptr, nullptr, nullptr, s);
+}
+
+int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, int64_t length, float out_scale_div,
+               float *d_wav, void *d_ws, size_t ws_bytes, void *stream) {
+    Workspace w;
+    int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
+    if (rc) return rc;
+    if (!d_codes || !d_wav || length <= 0) { set_error("null argument or non-positive length"); return BVC_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = run_decode(m, w, d_codes, nullptr, B, T, w.mel, nullptr, s))) return rc;
+    return run_vocoder(m, w, w.mel, B, T, length, out_scale_div, d_wav, -1, nullptr, nullptr, nullptr, s);
+}
+
+int bvc_test_linear(const float *d_x, const float *d_w, const float *d_bias, int32_t M, int32_t N, int32_t K,
+                    int32_t act, float *d_y, void *stream) {
+    Linear l; l.w = d_w; l.b = d_bias; l.in = K; l.out = N;
+    return launch_gemm_skinny(lin_params(l, d_x, K, M, d_y, N), act ? EPI_ELU : EPI_LINEAR, (hipStream_t)stream);
+}
+
+int bvc_test_linear_batched(const float *d_x, const float *d_w, const float *d_bias, int32_t M, int32_t N, int32_t K,
+                            int32_t act, float *d_y, void *stream) {
+    return launch_gemm_batched(d_x, K, d_w, K, d_bias, M, N, K, act, d_y, N, (hipStream_t)stream);
+}
+
+int bvc_test_vocoder_tap(const bvc_model *m, const float *d_mel, int32_t B, int64_t T, int32_t which, float *d_out,
+                         int64_t *out_numel_per_batch, void *d_ws, size_t ws_bytes, void *stream) {
+    Workspace w;
+    int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
+    if (rc) return rc;
+    if (which < 0 || which > 2 * m->cfg.n_up) { set_error("tap index out of range"); return BVC_EINVAL; }
+    const float *tap = nullptr;
+    int64_t len = 0;
+    int ch = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = run_vocoder(m, w, d_mel, B, T, 1, 1.0f, nullptr, which, &tap, &len, &ch, s))) return rc;
+    const long long n = (long long)B * len * ch;
+    if (out_numel_per_batch) *out_numel_per_batch = len * ch;
+    if (d_out) {
+        hipLaunchKernelGGL(tap_copy_kernel, dim3(1024), dim3(256), 0, s, tap, d_out, n);
+        BVC_HIP_TRY(hipGetLastError());
+    }
+    return BVC_OK;
+}
+
+}  // extern "C"

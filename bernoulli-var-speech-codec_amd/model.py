@@ -1,0 +1,287 @@
+"""Drop-in facade: ``BVRNNCodecModel(config_path, bvrnn_chkpt_path, vocoder_chkpt_path)`` with
+``encode(x, bitrate)``, ``decode(codes, length)``, ``forward(x, bitrate)`` - same names, argument
+meaning and error behaviour as the reference class (bvrnn_codec_model.py:19-76) - plus the two
+sub-operators the reference exposes as attributes (``model.bvrnn.encode/decode`` bvrnn.py:163-229,
+``model.vocoder(x, length)`` models.py:207-238) and ``mel_spectrogram`` (meldataset.py:60-95).
+
+All arithmetic runs in the gfx950 HIP library behind include/bvcodec.h; PyTorch only provides device
+memory and streams.  Inference only: outputs carry no autograd graph.  Tensors that live on another
+device (e.g. the CPU tensors of the reference's example.py) are moved to the model's GPU for the
+call and the result is returned on the caller's device.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _abi, weights
+from .config import DEFAULT_CONFIG, load_config
+
+_ROOT = os.path.abspath(os.path.dirname(__file__))
+default_config = DEFAULT_CONFIG
+default_chkpt_bvrnn = os.path.join(_ROOT, "chkpts", "bvrnn_var_bitrate_step200000")
+default_chkpt_vocoder = os.path.join(_ROOT, "chkpts", "bigvgan_causal_tiny_ftbvrnn_g_step3500000")
+
+SCALING = 10 ** (-10 / 20)      # bvrnn_codec_model.py:17
+
+
+def _as_device(device):
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("bvcodec needs an AMD GPU (gfx950): torch.cuda.is_available() is False and "
+                               "there is no CPU fallback")
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(f"bvcodec runs on the GPU only (got device '{device}')")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+class _Engine:
+    """One device-resident copy of the weights (a bvc_model handle) + its workspace."""
+
+    def __init__(self, conf, tensors, device):
+        self.lib = _abi.load()
+        self.device = device
+        self.conf = conf
+        v = conf["vocoder_config"]
+        cfg = _abi.BvcConfig()
+        cfg.num_mels, cfg.h_dim, cfg.z_dim = conf["num_mels"], conf["h_dim"], conf["z_dim"]
+        cfg.var_bit = 1 if conf["var_bit"] else 0
+        cfg.n_fft, cfg.hop, cfg.pad_left = conf["winsize"], conf["hopsize"], conf["mel_pad_left"]
+        cfg.sample_rate, cfg.fmin, cfg.fmax = conf["fs"], float(conf["fmin"]), float(conf["fmax"])
+        cfg.upsample_initial_channel = v["upsample_initial_channel"]
+        cfg.n_up = len(v["upsample_rates"])
+        for i, (u, k) in enumerate(zip(v["upsample_rates"], v["upsample_kernel_sizes"])):
+            cfg.up_rates[i], cfg.up_kernels[i] = u, k
+        cfg.n_resk = len(v["resblock_kernel_sizes"])
+        for j, (k, ds) in enumerate(zip(v["resblock_kernel_sizes"], v["resblock_dilation_sizes"])):
+            cfg.res_kernels[j] = k
+            for d in range(3):
+                cfg.res_dilations[j][d] = ds[d]
+        names = list(tensors)
+        arr = (_abi.BvcTensor * len(names))()
+        for i, n in enumerate(names):
+            t = tensors[n]
+            arr[i].name, arr[i].h_data, arr[i].numel = n.encode(), t.data_ptr(), t.numel()
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _abi.check(self.lib.bvc_model_create(ctypes.byref(cfg), arr, len(names), ctypes.byref(handle)))
+        self.handle = handle
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.bvc_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def workspace(self, B, T):
+        need = self.lib.bvc_workspace_bytes(self.handle, B, T)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel()
+
+    def stream(self):
+        return _abi.current_stream(self.device)
+
+    def num_frames(self, L):
+        return int(self.lib.bvc_num_frames(self.handle, L))
+
+    def vocoder_length(self, T):
+        return int(self.lib.bvc_vocoder_length(self.handle, T))
+
+
+def _prep(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class _OnDevice(nn.Module):
+    """Shared plumbing: lazily creates the engine on the module's device."""
+
+    def __init__(self, conf, tensors):
+        super().__init__()
+        self.conf = conf
+        self._tensors = tensors
+        self._engines = {}
+        self._device = None
+
+    def _apply(self, fn, *a, **k):              # follow .to('cuda:N') / .cuda(); there is no CPU residence
+        probe = fn(torch.empty(0))
+        if probe.device.type == "cuda":
+            self._device = _as_device(probe.device)
+        return super()._apply(fn, *a, **k)
+
+    def engine(self, like=None):
+        dev = self._device
+        if dev is None and like is not None and like.device.type == "cuda":
+            dev = like.device
+        dev = _as_device(dev)
+        if dev not in self._engines:
+            self._engines[dev] = _Engine(self.conf, self._tensors, dev)
+        return self._engines[dev]
+
+
+class BVRNN(_OnDevice):
+    """``BVRNN.encode`` / ``BVRNN.decode`` (bvrnn.py:163-229) on the HIP recurrent kernels."""
+
+    def __init__(self, conf, tensors, shared=None):
+        super().__init__(conf, tensors)
+        self.h_dim, self.z_dim, self.x_dim = conf["h_dim"], conf["z_dim"], conf["num_mels"]
+        self.varBit = bool(conf["var_bit"])
+        if shared is not None:
+            self._engines = shared
+
+    @torch.no_grad()
+    def encode(self, y, varBitrate, h, return_prob=False):
+        """y (B,T,x_dim), varBitrate (B,T) bits/frame, h (1,B,h_dim) -> (codes (B,T,z), all_h (B,T,h))."""
+        eng = self.engine(y)
+        out_dev = y.device
+        y = _prep(y, eng.device)
+        B, T, _ = y.shape
+        bits = _prep(varBitrate, eng.device) if varBitrate is not None else None
+        h0 = _prep(h.reshape(B, self.h_dim), eng.device)
+        codes = torch.empty(B, T, self.z_dim, device=eng.device)
+        all_h = torch.empty(B, T, self.h_dim, device=eng.device)
+        prob = torch.empty(B, T, self.z_dim, device=eng.device) if return_prob else None
+        ws, nws = eng.workspace(B, T)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.lib.bvc_bvrnn_encode(eng.handle, _abi.ptr(y), _abi.ptr(bits), _abi.ptr(h0), B, T,
+                                                _abi.ptr(codes), _abi.ptr(all_h), None, _abi.ptr(prob), ws, nws,
+                                                eng.stream()))
+        if return_prob:
+            return codes.to(out_dev), all_h.to(out_dev), prob.to(out_dev)
+        return codes.to(out_dev), all_h.to(out_dev)
+
+    @torch.no_grad()
+    def decode(self, z, h):
+        """z (B,T,z_dim), h (1,B,h_dim) -> (mel (B,T,x_dim), h (1,B,h_dim))."""
+        eng = self.engine(z)
+        out_dev = z.device
+        z = _prep(z, eng.device)
+        B, T, _ = z.shape
+        h0 = _prep(h.reshape(B, self.h_dim), eng.device)
+        mel = torch.empty(B, T, self.x_dim, device=eng.device)
+        hT = torch.empty(B, self.h_dim, device=eng.device)
+        ws, nws = eng.workspace(B, T)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.lib.bvc_bvrnn_decode(eng.handle, _abi.ptr(z), _abi.ptr(h0), B, T, _abi.ptr(mel),
+                                                _abi.ptr(hT), ws, nws, eng.stream()))
+        return mel.to(out_dev), hT.unsqueeze(0).to(out_dev)
+
+
+class BigVGAN(_OnDevice):
+    """``BigVGAN.forward(x, length)`` (models.py:207-238): x (B, num_mels, T) -> (B, 1, n)."""
+
+    def __init__(self, conf, tensors, shared=None):
+        super().__init__(conf, tensors)
+        if shared is not None:
+            self._engines = shared
+
+    @torch.no_grad()
+    def forward(self, x, length, _scale_div=1.0, _time_major=False):
+        eng = self.engine(x)
+        out_dev = x.device
+        mel = _prep(x if _time_major else x.permute(0, 2, 1), eng.device)        # kernels are time-major
+        B, T, _ = mel.shape
+        n = min(int(length), eng.vocoder_length(T))
+        wav = torch.empty(B, n, device=eng.device)
+        ws, nws = eng.workspace(B, T)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.lib.bvc_bigvgan(eng.handle, _abi.ptr(mel), B, T, int(length), float(_scale_div),
+                                           _abi.ptr(wav), ws, nws, eng.stream()))
+        return wav.unsqueeze(1).to(out_dev)
+
+
+class BVRNNCodecModel(_OnDevice):
+    def __init__(self, config_path=default_config, bvrnn_chkpt_path=default_chkpt_bvrnn,
+                 vocoder_chkpt_path=default_chkpt_vocoder):
+        '''
+        config_path: path to the toml config file
+        bvrnn_chkpt_path: path to the checkpoint of the BVRNN model
+        vocoder_chkpt_path: path to the checkpoint of the vocoder model
+        '''
+        conf = load_config(config_path)
+        vrnn_sd = weights.load_checkpoint(bvrnn_chkpt_path, "vrnn")
+        gen_sd = weights.load_checkpoint(vocoder_chkpt_path, "generator")
+        super().__init__(conf, weights.host_tensors(conf, vrnn_sd, gen_sd))
+        _abi.load()                                   # fail at construction if the HIP library is absent
+        self.bvrnn = BVRNN(conf, self._tensors, shared=self._engines)
+        self.vocoder = BigVGAN(conf, self._tensors, shared=self._engines)
+
+    def bits_per_frame(self, bitrate):
+        return float(np.round(bitrate * self.conf['hopsize'] / self.conf['fs']))   # bvrnn_codec_model.py:58
+
+    @torch.no_grad()
+    def mel_spectrogram(self, x, scale=SCALING):
+        """log-mel of x*scale as the facade computes it (bvrnn_codec_model.py:49-56): (B,L) -> (B,T,80)."""
+        eng = self.engine(x)
+        out_dev = x.device
+        x = _prep(x, eng.device)
+        if x.dim() != 2:
+            raise RuntimeError("expected a (batch, length) waveform")
+        B, L = x.shape
+        T = eng.num_frames(L)
+        if T <= 0:
+            raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension "
+                               f"(length {L} is too short for the reflect padding of the STFT front-end)")
+        mel = torch.empty(B, T, self.conf["num_mels"], device=eng.device)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.lib.bvc_stft_logmel(eng.handle, _abi.ptr(x), B, L, float(scale), _abi.ptr(mel),
+                                               eng.stream()))
+        return mel.to(out_dev)
+
+    @torch.no_grad()
+    def encode(self, x, bitrate):
+        '''
+        x: input waveform, shape (batch, length)
+        bitrate: target bitrate in bits per second, will be rounded to the nearest valid bitrate
+        '''
+        eng = self.engine(x)
+        out_dev = x.device
+        x = _prep(x, eng.device)
+        if x.dim() != 2:
+            raise RuntimeError("expected a (batch, length) waveform")
+        B, L = x.shape
+        T = eng.num_frames(L)
+        if T <= 0:
+            raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension "
+                               f"(length {L} is too short for the reflect padding of the STFT front-end)")
+        codes = torch.empty(B, T, self.conf["z_dim"], device=eng.device)
+        ws, nws = eng.workspace(B, T)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.lib.bvc_encode(eng.handle, _abi.ptr(x), B, L, float(SCALING), self.bits_per_frame(bitrate),
+                                          _abi.ptr(codes), ws, nws, eng.stream()))
+        return codes.to(out_dev)
+
+    @torch.no_grad()
+    def decode(self, codes, length):
+        '''
+        codes: latent binary codes, shape (batch, frames, z_dim)
+        length: length of the output waveform
+        '''
+        eng = self.engine(codes)
+        out_dev = codes.device
+        codes = _prep(codes, eng.device)
+        B, T, Z = codes.shape
+        if Z != self.conf["z_dim"]:
+            raise RuntimeError(f"codes must have {self.conf['z_dim']} values per frame, got {Z}")
+        n = min(int(length), eng.vocoder_length(T))
+        wav = torch.empty(B, n, device=eng.device)
+        ws, nws = eng.workspace(B, T)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.lib.bvc_decode(eng.handle, _abi.ptr(codes), B, T, int(length), float(SCALING),
+                                          _abi.ptr(wav), ws, nws, eng.stream()))
+        return wav.to(out_dev)
+
+    def forward(self, x, bitrate):
+        length = x.shape[1]
+        codes = self.encode(x, bitrate)
+        return self.decode(codes, length)

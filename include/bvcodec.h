@@ -1,0 +1,144 @@
+/* bvcodec.h - C ABI of libbvcodec_hip.so: the MI355X (gfx950) implementation of the
+ * BVRNNCodecModel encode/decode hot path.
+ *
+ * The reference (BenjSta/bernoulli-var-speech-codec) is pure Python/PyTorch and has NO FFI of its
+ * own; its boundary for this path is the Python class BVRNNCodecModel (bvrnn_codec_model.py:19-76).
+ * This header is the boundary the build adds underneath that class: each entry point names the
+ * reference call it replaces (file:line relative to the reference checkout).  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C, no torch/HIP types: `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *  - every pointer named d_* is DEVICE memory owned by the caller, contiguous float32;
+ *    every pointer named h_* is HOST memory;
+ *  - all compute entry points are asynchronous on `stream`, never allocate, never synchronise
+ *    (safe inside hipStreamBeginCapture), and use only the caller-provided workspace;
+ *  - return value: 0 = BVC_OK, negative = error code; bvc_last_error() gives the text
+ *    (thread-local); no C++ exception crosses the boundary;
+ *  - one in-flight call per (model, workspace); models are immutable after creation.
+ */
+#ifndef BVCODEC_H
+#define BVCODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BVC_ABI_VERSION 1
+
+enum {
+    BVC_OK = 0,
+    BVC_EINVAL = -1,      /* bad argument / unsupported shape */
+    BVC_ENOMEM = -2,      /* workspace too small or device allocation failed */
+    BVC_EHIP = -3,        /* HIP runtime error (see bvc_last_error) */
+    BVC_EMISSING = -4,    /* a required weight tensor is missing or has the wrong size */
+    BVC_ENODEVICE = -5    /* no gfx950 device visible */
+};
+
+/* Static description of the codec; mirrors the TOML keys the reference facade reads
+ * (configs/config_varBitRate.toml:21-29,35-37,39-56; bvrnn_codec_model.py:27-36,49-59). */
+typedef struct bvc_config {
+    int32_t num_mels;          /* 80 */
+    int32_t h_dim;             /* 1024 */
+    int32_t z_dim;             /* 64 */
+    int32_t var_bit;           /* 1: variable bits/frame mask (bvrnn.py:180-182,193-194) */
+    int32_t n_fft;             /* 1024 (== win) */
+    int32_t hop;               /* 256 */
+    int32_t pad_left;          /* mel_pad_left = 256 */
+    int32_t sample_rate;       /* 22050 */
+    float   fmin, fmax;        /* 0, 8000 */
+    int32_t upsample_initial_channel;      /* 128 */
+    int32_t n_up;                          /* 4 */
+    int32_t up_rates[8];                   /* 8,8,2,2 */
+    int32_t up_kernels[8];                 /* 16,16,4,4 (must be 2*rate) */
+    int32_t n_resk;                        /* 3 */
+    int32_t res_kernels[4];                /* 3,7,11 */
+    int32_t res_dilations[4][3];           /* 1,3,5 each */
+} bvc_config;
+
+/* One named HOST tensor (float32, contiguous, PyTorch layout).  Names are the reference's
+ * state_dict keys: BVRNN (bvrnn.py:30-83) "mean_mel","std_mel","phi_x.0.weight",...,
+ * "rnn.bias_hh_l0"; generator (models.py:132-205) with weight-norm ALREADY FOLDED by the caller:
+ * "conv_pre.weight","conv_pre.bias","ups.0.1.weight",...,"resblocks.0.convs1.0.weight",...,
+ * "resblocks.0.activations.0.alpha",...,"activation_post.alpha","conv_post.weight",...;
+ * plus "mel_basis" (num_mels x (n_fft/2+1), the librosa.filters.mel matrix of meldataset.py:68). */
+typedef struct bvc_tensor {
+    const char  *name;
+    const float *h_data;
+    int64_t      numel;
+} bvc_tensor;
+
+typedef struct bvc_model bvc_model;     /* opaque: device-resident, re-laid-out weights */
+
+int          bvc_abi_version(void);
+const char  *bvc_last_error(void);
+
+/* Replaces BVRNNCodecModel.__init__'s module construction + load_state_dict
+ * (bvrnn_codec_model.py:30-42): uploads and re-lays-out the weights on the current device. */
+int  bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t n_tensors,
+                      bvc_model **out);
+void bvc_model_destroy(bvc_model *m);
+
+/* Frames for L samples: floor(L / hop)  (torch.stft center=False after the reflect pad,
+ * meldataset.py:72-85).  Returns < 0 when L <= win - hop (reflect pad impossible). */
+int64_t bvc_num_frames(const bvc_model *m, int64_t L);
+/* Un-trimmed vocoder output length for T frames: 256*T + 294 for the shipped config
+ * (models.py:216-217 applied four times with padding=0). */
+int64_t bvc_vocoder_length(const bvc_model *m, int64_t T);
+/* Bytes of caller-provided device workspace needed by any entry point at batch B, T frames. */
+size_t  bvc_workspace_bytes(const bvc_model *m, int32_t B, int64_t T);
+
+/* mel_spectrogram(y*scale, ...) of meldataset.py:60-95 as called at bvrnn_codec_model.py:49-56,
+ * including the .permute(0,2,1): d_wav (B,L) -> d_mel (B,T,num_mels), natural-log mel. */
+int bvc_stft_logmel(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, float scale,
+                    float *d_mel, void *stream);
+
+/* BVRNN.encode (bvrnn.py:163-209).  d_mel (B,T,num_mels); d_bits (B,T) bits per frame (ignored
+ * when var_bit=0); d_h0 (B,h_dim) or NULL for zeros.  Outputs: d_codes (B,T,z_dim) in {0,1,0.5};
+ * optional d_all_h (B,T,h_dim) = state BEFORE each frame (bvrnn.py:205); optional d_hT (B,h_dim) =
+ * state after the last frame; optional d_prob (B,T,z_dim) = sigmoid output before rounding. */
+int bvc_bvrnn_encode(const bvc_model *m, const float *d_mel, const float *d_bits, const float *d_h0,
+                     int32_t B, int64_t T, float *d_codes, float *d_all_h, float *d_hT,
+                     float *d_prob, void *d_ws, size_t ws_bytes, void *stream);
+
+/* BVRNN.decode (bvrnn.py:211-229).  d_codes (B,T,z_dim) -> d_mel (B,T,num_mels), d_hT optional. */
+int bvc_bvrnn_decode(const bvc_model *m, const float *d_codes, const float *d_h0, int32_t B,
+                     int64_t T, float *d_mel, float *d_hT, void *d_ws, size_t ws_bytes,
+                     void *stream);
+
+/* BigVGAN.forward(x, length) (models.py:207-238) followed by `/ out_scale_div`
+ * (bvrnn_codec_model.py:71: .squeeze(1) / SCALING).  d_mel is TIME-major (B,T,num_mels), i.e. what
+ * bvc_bvrnn_decode emits (the reference permutes to (B,80,T) first).  d_wav (B, n_out) with
+ * n_out = min(length, bvc_vocoder_length(T)). */
+int bvc_bigvgan(const bvc_model *m, const float *d_mel, int32_t B, int64_t T, int64_t length,
+                float out_scale_div, float *d_wav, void *d_ws, size_t ws_bytes, void *stream);
+
+/* BVRNNCodecModel.encode (bvrnn_codec_model.py:44-62): scale, log-mel, bits/frame =
+ * bits_per_frame for every (b,t), zero initial state, BVRNN.encode.  d_wav (B,L) -> d_codes. */
+int bvc_encode(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, float scale,
+               float bits_per_frame, float *d_codes, void *d_ws, size_t ws_bytes, void *stream);
+
+/* BVRNNCodecModel.decode (bvrnn_codec_model.py:64-71): zero state, BVRNN.decode, vocoder, /scale. */
+int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, int64_t length,
+               float out_scale_div, float *d_wav, void *d_ws, size_t ws_bytes, void *stream);
+
+/* ---- building blocks exported for the parity tests (tests/ only; same kernels the path uses) */
+/* y[M,N] = act(x[M,K] @ w[N,K]^T + bias), act: 0 none, 1 ELU.  Recurrent-step kernel. */
+int bvc_test_linear(const float *d_x, const float *d_w, const float *d_bias, int32_t M, int32_t N,
+                    int32_t K, int32_t act, float *d_y, void *stream);
+/* same contract through the batched (all-frames) GEMM kernel */
+int bvc_test_linear_batched(const float *d_x, const float *d_w, const float *d_bias, int32_t M,
+                            int32_t N, int32_t K, int32_t act, float *d_y, void *stream);
+/* dump of one vocoder intermediate, channels-last: which = 0 conv_pre, 1+2i up_i, 2+2i stage_i.
+ * Runs the vocoder up to that point.  d_out (B, len, C); returns len*C via *out_numel_per_batch. */
+int bvc_test_vocoder_tap(const bvc_model *m, const float *d_mel, int32_t B, int64_t T, int32_t which,
+                         float *d_out, int64_t *out_numel_per_batch, void *d_ws, size_t ws_bytes,
+                         void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BVCODEC_H */

@@ -1,0 +1,308 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden vectors captured
+from the reference.  Needs the MI355X: run with ``-m gpu``.
+
+Bars (BASELINE.json north_star): code bits exact; waveform <= 1e-4 RMS.  The mel front-end and the
+intermediate float tensors carry their own tolerances, written next to each assert.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def env():
+    from gpu_common import make_model
+    return make_model(True, 1024)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from bvcodec import _abi
+    return _abi.load()
+
+
+# ----------------------------------------------------------------------------------- GEMM kernels
+@pytest.mark.parametrize("M", [1, 7, 16, 64, 100])
+@pytest.mark.parametrize("N,K", [(1024, 1024), (64, 1024), (1024, 64), (1024, 80), (80, 1024), (1024, 2048)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_skinny_linear(lib, M, N, K, act):
+    from bvcodec import _abi
+    g = torch.Generator().manual_seed(M * 131 + N + K + act)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    if act:
+        ref = torch.nn.functional.elu(ref)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    _abi.check(lib.bvc_test_linear(_abi.ptr(xd), _abi.ptr(wd), _abi.ptr(bd), M, N, K, act, _abi.ptr(y),
+                                   _abi.current_stream(torch.device(DEV))))
+    torch.cuda.synchronize()
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err < 2e-5, err          # fp32 accumulation over K <= 2048 of O(1) terms
+
+
+@pytest.mark.parametrize("M", [5, 128, 1000])
+@pytest.mark.parametrize("N,K", [(1024, 80), (1024, 1024), (64, 64)])
+def test_batched_linear(lib, M, N, K):
+    from bvcodec import _abi
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g)
+    ref = torch.nn.functional.elu(torch.nn.functional.linear(x.double(), w.double(), b.double()))
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    _abi.check(lib.bvc_test_linear_batched(_abi.ptr(xd), _abi.ptr(wd), _abi.ptr(bd), M, N, K, 1, _abi.ptr(y),
+                                           _abi.current_stream(torch.device(DEV))))
+    torch.cuda.synchronize()
+    assert (y.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+# ----------------------------------------------------------------------------------- front-end (A3)
+def _mel_close(got, ref):
+    """|d mel_lin| <= 1e-6 + 3e-6 * mel_lin: in quiet bands of tonal input the float32 FFT's own
+    rounding noise (different in every FFT implementation) dominates, so compare linearly."""
+    lg, lr = np.exp(got.astype(np.float64)), np.exp(ref.astype(np.float64))
+    return bool((np.abs(lg - lr) <= 1e-6 + 3e-6 * lr).all())
+
+
+@pytest.mark.parametrize("name", ["g1_mel", "g1_mel_short"])
+def test_frontend_vs_reference_golden(env, name):
+    model = env[0]
+    g = load_golden(name)
+    mel = model.mel_spectrogram(t(g["x"]).to(DEV)).cpu().numpy()          # (B,T,80)
+    ref = np.transpose(g["mel"], (0, 2, 1))
+    assert mel.shape == ref.shape
+    assert _mel_close(mel, ref)
+    if name == "g1_mel":      # broadband rows (noise, speech-like): plain log-domain tolerance
+        assert np.abs(mel[0] - ref[0]).max() < 2e-5
+        assert np.abs(mel[2] - ref[2]).max() < 1e-4
+
+
+def test_frontend_vs_float64_truth(env):
+    from oracle import frontend as ofe
+    from bvcodec import synth
+    model = env[0]
+    x = synth.synthetic_speech(4, 22050, seed=3, kind="speech")
+    mel = model.mel_spectrogram(x.to(DEV)).cpu().numpy()
+    m64 = ofe.log_mel(x.double() * ofe.SCALING, dtype=torch.float64).permute(0, 2, 1).numpy()
+    m32 = ofe.log_mel(x * ofe.SCALING).permute(0, 2, 1).numpy()
+    e_hip = np.abs(mel - m64).max()
+    e_ref = np.abs(m32 - m64).max()
+    assert mel.shape == (4, 86, 80)
+    assert e_hip < max(2 * e_ref, 2e-5), (e_hip, e_ref)     # as close to the truth as the fp32 reference path is
+
+
+# ----------------------------------------------------------------------------------- BVRNN (A5-A7)
+@pytest.mark.parametrize("tag,h_dim,var_bit", [("h1024_var", 1024, True), ("h1024_fix", 1024, False),
+                                              ("h64_var", 64, True)])
+def test_bvrnn_vs_reference_golden(tag, h_dim, var_bit):
+    from gpu_common import make_model
+    model = make_model(var_bit, h_dim)[0]
+    g = load_golden(f"g3_bvrnn_{tag}")
+    B = g["y"].shape[0]
+    h0 = torch.zeros(1, B, h_dim, device=DEV)
+    codes, all_h, prob = model.bvrnn.encode(t(g["y"]).to(DEV), t(g["bits"]).to(DEV), h0, return_prob=True)
+    assert np.abs(prob.cpu().numpy() - g["prob"]).max() < 2e-6
+    assert np.array_equal(codes.cpu().numpy(), g["codes"])                  # bit-exact codes
+    assert np.abs(all_h.cpu().numpy() - g["all_h"]).max() < 5e-6
+    mel, hT = model.bvrnn.decode(t(g["codes"]).to(DEV), h0)
+    assert np.abs(mel.cpu().numpy() - g["mel_hat"]).max() < 5e-5
+    assert np.abs(hT[0].cpu().numpy() - g["h_T"]).max() < 5e-6
+
+
+def test_bvrnn_free_running_vs_oracle(env):
+    """Larger free-running case: any differing bit must be a tie of the reference arithmetic
+    (|p-0.5| < 1e-5 in the oracle) at the FIRST differing frame of that utterance."""
+    from oracle import bvrnn as obv
+    model, conf, vr, _ = env
+    rng = np.random.default_rng(5)
+    B, T = 6, 48
+    y = torch.from_numpy((-4.0 + 1.6 * rng.standard_normal((B, T, 80))).astype(np.float32))
+    bits = torch.from_numpy(rng.integers(10, 65, size=(B, T)).astype(np.float32))
+    r = obv.encode(vr, y, bits, torch.zeros(B, 1024))
+    codes, all_h = model.bvrnn.encode(y.to(DEV), bits.to(DEV), torch.zeros(1, B, 1024, device=DEV))
+    codes = codes.cpu()
+    diff = (codes != r["codes"])
+    for b in range(B):
+        if diff[b].any():
+            t0 = int(diff[b].any(dim=1).nonzero()[0])
+            bad = diff[b, t0].nonzero().flatten()
+            assert ((r["prob"][b, t0, bad] - 0.5).abs() < 1e-5).all(), (b, t0)
+    # teacher-forced: restart every frame from the ORACLE's state -> every non-tie bit agrees
+    # (run per frame through the same kernels: T independent one-frame encodes)
+    mism = 0
+    for tt in range(0, T, 7):
+        c1, _ = model.bvrnn.encode(y[:, tt:tt + 1].to(DEV), bits[:, tt:tt + 1].to(DEV),
+                                   r["all_h"][:, tt].unsqueeze(0).to(DEV))
+        d = (c1.cpu()[:, 0] != r["codes"][:, tt])
+        assert ((r["prob"][:, tt][d] - 0.5).abs() < 1e-5).all()
+        mism += int(d.sum())
+    assert mism <= 2
+
+
+def test_bvrnn_chunked_decode_is_exact(env):
+    """BVRNN.decode carried over chunks (state hand-over) is bit-identical to one call."""
+    model = env[0]
+    rng = np.random.default_rng(9)
+    z = torch.from_numpy(rng.integers(0, 2, size=(3, 40, 64)).astype(np.float32)).to(DEV)
+    h0 = torch.zeros(1, 3, 1024, device=DEV)
+    full, hT = model.bvrnn.decode(z, h0)
+    a, ha = model.bvrnn.decode(z[:, :17], h0)
+    b, hb = model.bvrnn.decode(z[:, 17:], ha)
+    assert torch.equal(torch.cat([a, b], 1), full) and torch.equal(hb, hT)
+
+
+# ----------------------------------------------------------------------------------- BigVGAN (A8)
+def test_vocoder_taps_vs_reference_golden(env, lib):
+    from bvcodec import _abi
+    model = env[0]
+    from gpu_common import make_model
+    g = load_golden("g5_bigvgan_taps")
+    # the taps fixture uses generator seed 1235 == make_model's seed+1
+    mel = t(g["mel"]).permute(0, 2, 1).contiguous().to(DEV)                 # (1,T,80)
+    B, T = mel.shape[0], mel.shape[1]
+    eng = model.engine(mel)
+    ws, nws = eng.workspace(B, T)
+    names = ["conv_pre"]
+    for i in range(4):
+        names += [f"up{i}", f"stage{i}"]
+    for which, nm in enumerate(names):
+        n = ctypes.c_int64()
+        _abi.check(lib.bvc_test_vocoder_tap(eng.handle, _abi.ptr(mel), B, T, which, None, ctypes.byref(n), ws, nws,
+                                            eng.stream()))
+        out = torch.full((B, n.value), float("nan"), device=DEV)
+        _abi.check(lib.bvc_test_vocoder_tap(eng.handle, _abi.ptr(mel), B, T, which, _abi.ptr(out), ctypes.byref(n),
+                                            ws, nws, eng.stream()))
+        torch.cuda.synchronize()
+        if nm.startswith("stage"):
+            i = int(nm[5:])
+            ref = (g[f"res{i}_0"] + g[f"res{i}_1"] + g[f"res{i}_2"]) / 3
+        else:
+            ref = g[nm]
+        C = ref.shape[1]
+        got = out.cpu().numpy().reshape(B, -1, C).transpose(0, 2, 1)          # -> (B,C,L)
+        assert got.shape == ref.shape, (nm, got.shape, ref.shape)
+        err = np.abs(got - ref).max()
+        scale = max(1.0, np.abs(ref).max())
+        assert err < 2e-5 * scale, (nm, err, scale)
+
+
+def test_vocoder_vs_reference_golden(env):
+    model = env[0]
+    g = load_golden("g5_bigvgan")
+    mel = t(g["mel"]).to(DEV)                                                 # (B,80,T) like the reference
+    T = mel.shape[2]
+    for length in (8192, 8392, 10 ** 9):
+        w = model.vocoder(mel, length).cpu().numpy()
+        ref = g[f"wav_{length}"]
+        assert w.shape == ref.shape and w.shape[2] == min(length, 256 * T + 294)
+        assert np.sqrt(((w - ref) ** 2).mean()) < 1e-5
+        assert np.abs(w - ref).max() < 1e-4
+
+
+# ----------------------------------------------------------------------------------- facade (A2, A9)
+@pytest.mark.parametrize("tag", ["var", "fix"])
+def test_facade_vs_reference_golden(tag):
+    from gpu_common import make_model
+    model = make_model(tag == "var", 1024)[0]
+    g = load_golden(f"g6_e2e_{tag}")
+    x = t(g["x"]).to(DEV)
+    for br in ((3000, 1500, 6000) if tag == "var" else (3000,)):
+        codes = model.encode(x, br)
+        assert codes.shape == g[f"codes_{br}"].shape and codes.dtype == torch.float32
+        assert np.array_equal(codes.cpu().numpy(), g[f"codes_{br}"]), br       # bit-exact codes
+        wav = model.decode(t(g[f"codes_{br}"]).to(DEV), x.shape[1])
+        ref = g[f"wav_{br}"]
+        assert wav.shape == ref.shape
+        assert np.sqrt(((wav.cpu().numpy() - ref) ** 2).mean()) < 1e-4         # north_star waveform bar
+    full = model(x, 3000)
+    assert np.sqrt(((full.cpu().numpy() - g["wav_3000"]) ** 2).mean()) < 1e-4
+    un = model.decode(t(g["codes_3000"]).to(DEV), 10 ** 9)
+    assert un.shape == g["wav_untrimmed_3000"].shape
+    assert np.sqrt(((un.cpu().numpy() - g["wav_untrimmed_3000"]) ** 2).mean()) < 1e-4
+
+
+def test_facade_accepts_cpu_tensors_and_returns_on_caller_device(env):
+    model = env[0]
+    g = load_golden("g6_e2e_var")
+    x = t(g["x"])[:1]
+    codes = model.encode(x, 3000)
+    assert codes.device.type == "cpu" and np.array_equal(codes.numpy(), g["codes_3000"][:1])
+
+
+def test_facade_error_behaviour(env):
+    model = env[0]
+    with pytest.raises(RuntimeError):
+        model.encode(torch.zeros(1, 512, device=DEV), 3000)      # reflect pad needs L > 512
+    with pytest.raises(RuntimeError):
+        model.decode(torch.zeros(1, 4, 63, device=DEV), 1000)
+
+
+# ----------------------------------------------------------------------------------- properties at size
+def test_batch_invariance_and_determinism(env):
+    """An utterance's codes and waveform do not depend on what else is in the batch or on the run."""
+    from bvcodec import synth
+    model = env[0]
+    x = synth.synthetic_speech(24, 256 * 40 + 13, seed=7, kind="speech").to(DEV)
+    c_all = model.encode(x, 3000)
+    c_again = model.encode(x, 3000)
+    assert torch.equal(c_all, c_again)
+    c_sub = model.encode(x[5:8], 3000)
+    assert torch.equal(c_all[5:8], c_sub)
+    w_all = model.decode(c_all, x.shape[1])
+    w_sub = model.decode(c_all[5:8], x.shape[1])
+    assert torch.equal(w_all[5:8], w_sub)
+    assert torch.isfinite(w_all).all()
+
+
+def test_vocoder_is_causal(env):
+    """First 256*T' samples depend only on the first T' frames."""
+    model = env[0]
+    rng = np.random.default_rng(3)
+    mel = torch.from_numpy((-4 + 1.6 * rng.standard_normal((2, 80, 24))).astype(np.float32)).to(DEV)
+    full = model.vocoder(mel, 10 ** 9)
+    part = model.vocoder(mel[:, :, :10].contiguous(), 10 ** 9)
+    assert torch.equal(full[:, :, :2560], part[:, :, :2560])
+
+
+def test_full_size_config_roundtrip_properties():
+    """BASELINE configs[1] shape (64 x 5 s @ 3 kbit/s) through encode+decode: shapes, value sets,
+    finiteness, and agreement of a sampled utterance with the oracle."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    from oracle import codec as ocodec
+    model, conf, vr, ge = make_model(True, 1024)
+    x = synth.synthetic_speech(64, 110250, seed=0, kind="noise").to(DEV)
+    codes = model.encode(x, 3000)
+    assert codes.shape == (64, 430, 64)
+    vals = torch.unique(codes).cpu().tolist()
+    assert set(vals) <= {0.0, 0.5, 1.0}
+    assert (codes[:, :, 35:] == 0.5).all() and (codes[:, :, :35] != 0.5).all()
+    wav = model.decode(codes, x.shape[1])
+    assert wav.shape == (64, 110250) and torch.isfinite(wav).all()
+    # one utterance, first second, against the oracle (free-running; ties excluded as above)
+    oc = ocodec.OracleCodec(conf, vr, ge)
+    r = oc.encode(x[3:4, :22050].cpu(), 3000, full=True)
+    got = model.encode(x[3:4, :22050], 3000).cpu()
+    diff = got != r["codes"]
+    if diff.any():
+        t0 = int(diff[0].any(dim=1).nonzero()[0])
+        assert ((r["prob"][0, t0][diff[0, t0]] - 0.5).abs() < 1e-5).all()
+    ref_wav = oc.decode(got, 22050)
+    w = model.decode(got.to(DEV), 22050).cpu()
+    assert float((w - ref_wav).pow(2).mean().sqrt()) < 1e-4
