@@ -40,9 +40,10 @@ def gemm():
         g = torch.Generator().manual_seed(1)
         x = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / np.sqrt(K); b = torch.randn(N, generator=g)
         ref = torch.nn.functional.elu(torch.nn.functional.linear(x.double(), w.double(), b.double()))
+        xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
         for name, fn in (("skinny", lib.bvc_test_linear), ("batched", lib.bvc_test_linear_batched)):
             y = torch.full((M, N), float("nan"), device=DEV)
-            _abi.check(fn(_abi.ptr(x.to(DEV)), _abi.ptr(w.to(DEV)), _abi.ptr(b.to(DEV)), M, N, K, 1, _abi.ptr(y),
+            _abi.check(fn(_abi.ptr(xd), _abi.ptr(wd), _abi.ptr(bd), M, N, K, 1, _abi.ptr(y),
                           _abi.current_stream(torch.device(DEV))))
             torch.cuda.synchronize()
             report(f"gemm {name} M{M} N{N} K{K}", y.cpu().numpy(), ref.numpy())
