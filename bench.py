@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the BVRNNCodecModel encode+decode hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: ``encode(x, 3000)`` then
+``decode(codes, L)`` on BASELINE.json configs[1] - 64 synthetic 5 s utterances at 22.05 kHz,
+config_varBitRate @ 3 kbit/s (35 bits/frame) - PER GPU (weak scaling: utterances are independent,
+each rank runs its own batch with no data-path collective; one RCCL all-gather of the decoded
+waveforms per step is the "final gather" of the north star).  Inputs are resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line: metric/value (audio-seconds coded per wall-second,
+whole job), plus
+
+  roofline     - the dominant kernel family, timed in situ with hipEvent pairs around sampled
+                 launches inside the real schedule (bvc_probe_*), algorithmic FLOPs per launch from
+                 SURVEY.md 8(d), against the fp32 MFMA peak of MI355X_MICROARCH.md
+  cpu_baseline - the CPU oracle (oracle/, PyTorch-CPU port of the reference op sequence) timed on
+                 the host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from bvcodec import BVRNNCodecModel, _abi, config, dist as bdist, synth   # noqa: E402
+
+FS = 22050
+BATCH = 64
+SECONDS = 5.0
+BITRATE = 3000
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix = vector peak
+PROBE_NAMES = {1: "gemm_skinny_kernel<linear> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<gru> (GRU cell)",
+               3: "conv_mfma_kernel (BigVGAN conv)", 4: "gemm_batched_kernel (phi_x, all frames)",
+               5: "stft_logmel_kernel", 6: "conv_post_kernel"}
+
+
+def flops_per_step(conf, B, T):
+    """Algorithmic FLOPs (2*MAC) of one encode+decode step, per kernel family."""
+    H, Z, X = conf["h_dim"], conf["z_dim"], conf["num_mels"]
+    enc_lin = 2 * H * H + H * H + H * Z + (Z * H + 2 * H * H) + (2 * H * H + 2 * H * H + H * X) + (X * H + 2 * H * H)
+    dec_lin = (Z * H + 2 * H * H) + (2 * H * H + 2 * H * H + H * X) + (X * H + 2 * H * H)
+    gru = 3 * H * (2 * H) + 3 * H * H
+    phix = X * H + 2 * H * H
+    v = conf["vocoder_config"]
+    ch, rate, voc = v["upsample_initial_channel"], 1, conf["num_mels"] * v["upsample_initial_channel"] * 7
+    for u, k in zip(v["upsample_rates"], v["upsample_kernel_sizes"]):
+        rate *= u
+        voc += rate * ch * (ch // 2) * (k // u)                      # transposed conv
+        ch //= 2
+        voc += rate * ch * ch * sum(v["resblock_kernel_sizes"]) * 6  # 3 AMP blocks x 3 x 2 convs
+    post = rate * ch * 7
+    BT = B * T
+    return {
+        1: (2.0 * BT * (enc_lin + dec_lin), T * (13 + 10)),
+        2: (2.0 * BT * 2 * gru, 2 * T),
+        3: (2.0 * BT * voc, 1 + len(v["upsample_rates"]) * (1 + 18)),
+        4: (2.0 * BT * phix, 3),
+        5: (2.0 * BT * 5 * 512 * 9 * 1.0, 1),
+        6: (2.0 * BT * post, 1),
+    }
+
+
+def cpu_baseline(conf):
+    """Oracle (PyTorch-CPU port of the reference op sequence) on a bounded sample: 8 x 5 s."""
+    from oracle import codec as ocodec
+    threads = min(16, os.cpu_count() or 1)      # the 1-GPU box's CPU share is 16 cores
+    torch.set_num_threads(threads)
+    oc = ocodec.OracleCodec(conf, synth.bvrnn_state_dict(conf, 1234), synth.generator_state_dict(conf, 1235))
+    b = 8
+    x = synth.synthetic_speech(b, int(FS * SECONDS), seed=0, kind="noise")
+    oc.forward(x[:1, :FS], BITRATE)                                  # warm-up (thread pools, mkldnn)
+    t0 = time.time()
+    oc.forward(x, BITRATE)
+    dt = time.time() - t0
+    return {"value": round(b * SECONDS / dt, 3), "unit": "audio-seconds/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{b} x {SECONDS:g} s utterances, encode+decode @ {BITRATE} bit/s, "
+                                      f"oracle (PyTorch-CPU eager fp32), {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=SECONDS)
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    rank, world, device = bdist.init_from_env()
+    if world != a.gpus and rank == 0:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    assert device.type == "cuda", "bench.py needs an MI355X"
+    conf = config.load_config(config.DEFAULT_CONFIG)
+    ckdir = tempfile.mkdtemp(prefix=f"bvc_bench_r{rank}_")
+    p1, p2 = synth.write_checkpoints(conf, ckdir, seed=1234)
+    model = BVRNNCodecModel(config.DEFAULT_CONFIG, p1, p2).to(device)
+
+    L = int(FS * a.seconds)
+    B = a.batch
+    x = synth.synthetic_speech(B, L, seed=rank, kind="noise").to(device)      # resident before timing
+    gathered = torch.empty(world * B, L, device=device) if (world > 1 and not a.no_gather) else None
+
+    def step():
+        codes = model.encode(x, BITRATE)
+        wav = model.decode(codes, L)
+        if gathered is not None:
+            torch.distributed.all_gather_into_tensor(gathered, wav)
+        return codes, wav
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        codes, wav = step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(wav).all() and codes.shape[2] == conf["z_dim"]
+
+    T = codes.shape[1]
+    out = {
+        "metric": "audio-seconds coded per wall-second (encode+decode), 22.05 kHz @ 3 kbit/s",
+        "value": round(world * B * a.seconds * a.steps / elapsed, 2),
+        "unit": "audio-seconds/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: batch {B} x {a.seconds:g} s utterances per GPU, "
+                               f"config_varBitRate @ {BITRATE} bit/s (35 bits/frame), full encode -> BigVGAN decode",
+                   "frames_per_utterance": T, "weights": "seeded synthetic (checkpoints are LFS pointers)",
+                   "gather": "rccl all_gather of decoded waveforms" if gathered is not None else "none"},
+    }
+
+    if rank == 0 and not a.no_roofline:
+        lib = _abi.load()
+        fam = flops_per_step(conf, B, T)
+        rows = {}
+        for kind in (1, 2, 3, 4, 5, 6):
+            every = 7 if kind == 1 else 1
+            _abi.check(lib.bvc_probe_begin(kind, every, 4096))
+            step()
+            mean, mn, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
+            _abi.check(lib.bvc_probe_end(ctypes.byref(mean), ctypes.byref(mn), ctypes.byref(n)))
+            fl, launches = fam[kind]
+            rows[kind] = {"kernel": PROBE_NAMES[kind], "launches_per_step": launches, "sampled": n.value,
+                          "mean_us": round(mean.value, 3), "total_ms": round(mean.value * launches / 1e3, 3),
+                          "tflops": round(fl / launches / (mean.value * 1e-6) / 1e12, 3) if mean.value else 0.0}
+        dom = max(rows, key=lambda k: rows[k]["total_ms"])
+        r = rows[dom]
+        out["roofline"] = {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(r["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                           "traffic": None, "kernel": r["kernel"], "mean_launch_us": r["mean_us"],
+                           "launches_per_step": r["launches_per_step"],
+                           "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32); algorithmic FLOPs per launch / "
+                                   "in-situ hipEvent launch duration"}
+        out["kernel_families"] = rows
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(conf)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

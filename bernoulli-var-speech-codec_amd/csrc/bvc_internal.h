@@ -20,6 +20,16 @@ void set_error(const char *fmt, ...);
         }                                                                              \
     } while (0)
 
+// ------------------------------------------------------------------ in-situ kernel timing (bench only)
+// bvc_probe_begin(kind, every, max) makes every `every`-th launch of kernel family `kind` be
+// bracketed by a hipEvent pair on its own stream; bvc_probe_end() reports the mean elapsed time.
+enum ProbeKind { PK_NONE = 0, PK_LINEAR = 1, PK_GRU = 2, PK_CONV = 3, PK_BATCHED = 4, PK_STFT = 5, PK_POST = 6 };
+struct ProbeScope {
+    hipStream_t s; int slot;
+    ProbeScope(int kind, hipStream_t stream);
+    ~ProbeScope();
+};
+
 // ------------------------------------------------------------------ skinny / recurrent GEMM (k_gemm.hip)
 // One K-segment of a (possibly concatenated) input:  acc[grp] += x[M,K] @ w[rows,K]^T
 struct GemmSeg {

@@ -21,6 +21,24 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// ---- sampled hipEvent probes around kernel launches (bench instrumentation, off by default)
+struct ProbeState {
+    int kind = PK_NONE, every = 1, counter = 0, used = 0;
+    std::vector<hipEvent_t> ev;          // pairs
+};
+static ProbeState g_probe;
+
+ProbeScope::ProbeScope(int kind, hipStream_t stream) : s(stream), slot(-1) {
+    if (g_probe.kind != kind) return;
+    if ((g_probe.counter++ % g_probe.every) != 0) return;
+    if ((size_t)(g_probe.used + 1) * 2 > g_probe.ev.size()) return;
+    slot = g_probe.used++;
+    (void)hipEventRecord(g_probe.ev[2 * slot], s);
+}
+ProbeScope::~ProbeScope() {
+    if (slot >= 0) (void)hipEventRecord(g_probe.ev[2 * slot + 1], s);
+}
+
 struct Linear { const float *w = nullptr, *b = nullptr; int in = 0, out = 0; };
 
 struct AmpPair { ConvLayer c1, c2; };
@@ -660,6 +678,36 @@ int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, i
     hipStream_t s = (hipStream_t)stream;
     if ((rc = run_decode(m, w, d_codes, nullptr, B, T, w.mel, nullptr, s))) return rc;
     return run_vocoder(m, w, w.mel, B, T, length, out_scale_div, d_wav, -1, nullptr, nullptr, nullptr, s);
+}
+
+int bvc_probe_begin(int32_t kind, int32_t sample_every, int32_t max_samples) {
+    if (kind <= PK_NONE || kind > PK_POST || sample_every < 1 || max_samples < 1) {
+        set_error("bvc_probe_begin: bad arguments");
+        return BVC_EINVAL;
+    }
+    while ((int)g_probe.ev.size() < 2 * max_samples) {
+        hipEvent_t e;
+        BVC_HIP_TRY(hipEventCreate(&e));
+        g_probe.ev.push_back(e);
+    }
+    g_probe.kind = kind; g_probe.every = sample_every; g_probe.counter = 0; g_probe.used = 0;
+    return BVC_OK;
+}
+
+int bvc_probe_end(double *mean_us, double *min_us, int32_t *n_samples) {
+    g_probe.kind = PK_NONE;
+    BVC_HIP_TRY(hipDeviceSynchronize());
+    double sum = 0.0, mn = 1e30;
+    for (int i = 0; i < g_probe.used; ++i) {
+        float ms = 0.0f;
+        BVC_HIP_TRY(hipEventElapsedTime(&ms, g_probe.ev[2 * i], g_probe.ev[2 * i + 1]));
+        sum += ms * 1e3;
+        if (ms * 1e3 < mn) mn = ms * 1e3;
+    }
+    if (mean_us) *mean_us = g_probe.used ? sum / g_probe.used : 0.0;
+    if (min_us) *min_us = g_probe.used ? mn : 0.0;
+    if (n_samples) *n_samples = g_probe.used;
+    return BVC_OK;
 }
 
 int bvc_test_linear(const float *d_x, const float *d_w, const float *d_bias, int32_t M, int32_t N, int32_t K,

@@ -154,6 +154,7 @@ int launch_stft_logmel(const FrontendTables &t, const float *wav, int B, long lo
     const long long nblocks = (nframes + 3) / 4;
     const int grid = (int)(nblocks > 2048 ? 2048 : nblocks);
     const size_t lds = (size_t)(4 * WAVE_LDS * 2 + 4 * MAG_LDS) * sizeof(float);
+    ProbeScope probe(PK_STFT, s);
     hipLaunchKernelGGL(stft_logmel_kernel, dim3(grid), dim3(256), lds, s, t, wav, L, T, nframes, pad_left,
                        scale, mel);
     BVC_HIP_TRY(hipGetLastError());

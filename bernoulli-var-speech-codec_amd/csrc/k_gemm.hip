@@ -184,6 +184,7 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s) {
     const int n_tiles = p.N / 16, m_tiles = (p.M + 15) / 16;
     const int grid = 8 * ((n_tiles + 7) / 8) * m_tiles;
     constexpr int NW = 8;
+    ProbeScope probe(epi == EPI_GRU ? PK_GRU : PK_LINEAR, s);
     if (epi == EPI_GRU) {
         const size_t lds = (size_t)NW * 6 * 256 * sizeof(float);
         hipLaunchKernelGGL((gemm_skinny_kernel<3, 2, NW, 4>), dim3(grid), dim3(NW * 64), lds, s, p, epi);
@@ -270,6 +271,7 @@ int launch_gemm_batched(const float *x, long long ldx, const float *w, long long
         return BVC_EINVAL;
     }
     dim3 grid((N + 127) / 128, (M + 127) / 128);
+    ProbeScope probe(PK_BATCHED, s);
     if (act == 1)
         hipLaunchKernelGGL(gemm_batched_kernel<1>, grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy);
     else

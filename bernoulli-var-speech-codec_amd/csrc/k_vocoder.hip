@@ -149,6 +149,7 @@ static int launch_one(const ConvArgs &a, int B, hipStream_t s) {
     if (lds > 160 * 1024) { set_error("conv tile needs %zu B of LDS", lds); return BVC_EINVAL; }
     dim3 grid((unsigned)(k.tiles_per_batch * (long long)B), (unsigned)((a.ntiles + NTW - 1) / NTW));
     auto kern = conv_mfma_kernel<CIN, NTW, MT>;
+    ProbeScope probe(PK_CONV, s);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
@@ -235,6 +236,7 @@ int launch_conv_post(const float *in, long long Lin, int C, int ks, const float 
     if (C != 8) { set_error("conv_post: unsupported channel count %d", C); return BVC_EINVAL; }
     const int tiles = (int)((n_out + 255) / 256);
     const size_t lds = (size_t)(256 + ks - 1) * C * sizeof(float);
+    ProbeScope probe(PK_POST, s);
     hipLaunchKernelGGL(conv_post_kernel<8>, dim3((unsigned)(tiles * (long long)B)), dim3(256), lds, s, in, Lin, ks,
                        w, bias, act_a, act_ib, div, wav, n_out, tiles);
     BVC_HIP_TRY(hipGetLastError());

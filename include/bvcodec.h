@@ -138,6 +138,14 @@ int bvc_test_vocoder_tap(const bvc_model *m, const float *d_mel, int32_t B, int6
                          float *d_out, int64_t *out_numel_per_batch, void *d_ws, size_t ws_bytes,
                          void *stream);
 
+/* ---- bench instrumentation: in-situ hipEvent timing of one kernel family inside the real schedule.
+ * kind: 1 recurrent linear layer, 2 GRU cell, 3 vocoder conv, 4 batched phi_x GEMM, 5 STFT/mel,
+ * 6 conv_post.  Every `sample_every`-th launch of that family is bracketed by an event pair on its
+ * own stream until `max_samples` pairs are used; bvc_probe_end synchronises the device and returns
+ * the mean / min elapsed microseconds.  Not thread-safe; off by default. */
+int bvc_probe_begin(int32_t kind, int32_t sample_every, int32_t max_samples);
+int bvc_probe_end(double *mean_us, double *min_us, int32_t *n_samples);
+
 #ifdef __cplusplus
 }
 #endif
