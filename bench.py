@@ -39,8 +39,8 @@ BATCH = 64
 SECONDS = 5.0
 BITRATE = 3000
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix = vector peak
-PROBE_NAMES = {1: "gemm_skinny_kernel<linear> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<gru> (GRU cell)",
-               3: "conv_mfma_kernel (BigVGAN conv)", 4: "gemm_batched_kernel (phi_x, all frames)",
+PROBE_NAMES = {1: "gemm_skinny_kernel<1,1,*> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<3,2,16,3> (GRU cell)",
+               3: "conv_mfma_kernel (BigVGAN conv)", 4: "gemm_batched_kernel (phi_x / phi_z over all frames)",
                5: "stft_logmel_kernel", 6: "conv_post_kernel"}
 
 
@@ -157,24 +157,49 @@ def main():
         lib = _abi.load()
         fam = flops_per_step(conf, B, T)
         rows = {}
-        for kind in (1, 2, 3, 4, 5, 6):
-            every = 7 if kind == 1 else 1
-            _abi.check(lib.bvc_probe_begin(kind, every, 4096))
+
+        def kread(lo, hi):
+            mean, mn, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
+            _abi.check(lib.bvc_kprobe_read(lo, hi, ctypes.byref(mean), ctypes.byref(mn), ctypes.byref(n)))
+            return mean.value, n.value
+
+        # recurrent kernels are replayed from a hipGraph: in-kernel wall-clock stamps (bvc_kprobe_*)
+        _abi.check(lib.bvc_kprobe_enable(1))
+        c_ = model.encode(x, BITRATE)
+        e_lin, e_nl = kread(0, 13)
+        e_gru, e_ng = kread(13, 14)
+        model.decode(c_, L)
+        d_lin, d_nl = kread(0, 7)
+        d_gru, d_ng = kread(7, 8)
+        _abi.check(lib.bvc_kprobe_enable(0))
+        fam[1] = (fam[1][0] - 2.0 * B * T * (conf["z_dim"] * conf["h_dim"] + 2 * conf["h_dim"] ** 2), T * (13 + 7))
+        fam[4] = (fam[4][0] + 2.0 * B * T * (conf["z_dim"] * conf["h_dim"] + 2 * conf["h_dim"] ** 2), 6)
+        for kind, mean, n in ((1, (e_lin * e_nl + d_lin * d_nl) / max(1, e_nl + d_nl), e_nl + d_nl),
+                              (2, (e_gru * e_ng + d_gru * d_ng) / max(1, e_ng + d_ng), e_ng + d_ng)):
+            fl, launches = fam[kind]
+            rows[kind] = {"kernel": PROBE_NAMES[kind], "launches_per_step": launches, "sampled": n,
+                          "mean_us": round(mean, 3), "total_ms": round(mean * launches / 1e3, 3),
+                          "tflops": round(fl / launches / (mean * 1e-6) / 1e12, 3) if mean else 0.0,
+                          "timer": "in-kernel wall_clock64 (first workgroup start -> last workgroup end)"}
+        for kind in (3, 4, 5, 6):               # eagerly launched kernels: hipEvent pairs around every launch
+            _abi.check(lib.bvc_probe_begin(kind, 1, 4096))
             step()
             mean, mn, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
             _abi.check(lib.bvc_probe_end(ctypes.byref(mean), ctypes.byref(mn), ctypes.byref(n)))
             fl, launches = fam[kind]
             rows[kind] = {"kernel": PROBE_NAMES[kind], "launches_per_step": launches, "sampled": n.value,
                           "mean_us": round(mean.value, 3), "total_ms": round(mean.value * launches / 1e3, 3),
-                          "tflops": round(fl / launches / (mean.value * 1e-6) / 1e12, 3) if mean.value else 0.0}
+                          "tflops": round(fl / launches / (mean.value * 1e-6) / 1e12, 3) if mean.value else 0.0,
+                          "timer": "hipEvent pair on the launch stream"}
         dom = max(rows, key=lambda k: rows[k]["total_ms"])
         r = rows[dom]
         out["roofline"] = {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(r["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
                            "traffic": None, "kernel": r["kernel"], "mean_launch_us": r["mean_us"],
                            "launches_per_step": r["launches_per_step"],
+                           "timer": r["timer"],
                            "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32); algorithmic FLOPs per launch / "
-                                   "in-situ hipEvent launch duration"}
+                                   "launch duration measured in situ inside the real schedule"}
         out["kernel_families"] = rows
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(conf)

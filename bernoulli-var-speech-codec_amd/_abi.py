@@ -52,6 +52,9 @@ SIGNATURES = {
     "bvc_probe_begin": (ctypes.c_int, [_i32, _i32, _i32]),
     "bvc_probe_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(_i32)]),
+    "bvc_kprobe_enable": (ctypes.c_int, [_i32]),
+    "bvc_kprobe_read": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(_i32)]),
     "bvc_test_linear": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "bvc_test_linear_batched": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "bvc_test_vocoder_tap": (ctypes.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, ctypes.POINTER(_i64), _vp, _sz, _vp]),

@@ -31,10 +31,37 @@ struct ProbeScope {
 };
 
 // ------------------------------------------------------------------ skinny / recurrent GEMM (k_gemm.hip)
+// Per-call dynamic state, resident in device memory.  The recurrent-step kernels are captured ONCE
+// into a hipGraph and replayed for every frame, so nothing that changes per call or per frame may be a
+// kernel argument: caller tensors are reached through this descriptor and the frame index `t` is a
+// device-side counter advanced by step_advance_kernel at the end of every step.
+enum DescSlot { DS_PX = 0, DS_CODES = 1, DS_BITS = 2, DS_PROB = 3, DS_ALLH = 4, DS_MEL = 5, DS_PZ = 6, DS_NSLOT = 8 };
+struct CallDesc {
+    float *p[DS_NSLOT];              // base pointers of the (B, T, dim) tensors of this call (may be null)
+    unsigned long long *probe;       // in-kernel timing slots [2 * launches] or null (bench only)
+    long long T;                     // frames per utterance
+    int t;                           // current frame
+    int nodes_per_step;              // kernels per step (probe slot = t * nodes_per_step + node)
+};
+
+// A pointer whose value depends on the frame counter.
+//   kind 0 (static) : base, row stride ld
+//   kind 1 (frame)  : desc->p[sel] + (t + toff) * dim, row stride T * dim; invalid outside [0, T) or if null
+//   kind 2 (parity) : base + (((t + toff) & 1) ? poff : 0), row stride ld      (GRU state ping-pong)
+struct DynPtr {
+    float *base;
+    long long ld;
+    long long poff;
+    int kind, sel, dim, toff;
+};
+inline DynPtr dp_static(const float *p, long long ld) { return DynPtr{const_cast<float *>(p), ld, 0, 0, 0, 0, 0}; }
+inline DynPtr dp_frame(int sel, int dim, int toff = 0) { return DynPtr{nullptr, 0, 0, 1, sel, dim, toff}; }
+inline DynPtr dp_parity(float *p, long long ld, long long poff, int flip) { return DynPtr{p, ld, poff, 2, 0, 0, flip}; }
+inline DynPtr dp_null() { return DynPtr{nullptr, 0, 0, 0, 0, 0, 0}; }
+
 // One K-segment of a (possibly concatenated) input:  acc[grp] += x[M,K] @ w[rows,K]^T
 struct GemmSeg {
-    const float *x;      // [M][ldx]
-    long long    ldx;
+    DynPtr       x;      // [M][ld]
     const float *w;      // [rows][ldw], row = gate*gate_rows + n
     long long    ldw;
     int          K;      // multiple of 16
@@ -56,15 +83,18 @@ struct GemmParams {
     long long gate_rows;       // row distance between gates inside w (GRU: h_dim)
     const float *bias0;        // group 0 bias [gates*N]
     const float *bias1;        // group 1 bias (GRU only)
-    float  *y;   long long ldy;
-    float  *y2;  long long ldy2;     // optional second output
-    float  *y3;  long long ldy3;     // optional third output (CODE: prob dump)
-    const float *aux; long long ldaux;   // CODE: bits per frame (one per row); GRU: previous h [M][ldaux]
+    DynPtr  y, y2, y3;         // outputs (y2/y3 optional)
+    DynPtr  aux;               // CODE: bits per frame (one per row); GRU: previous h
     const float *mean; const float *stdv; // MEL epilogue
     int     var_bit;
+    const CallDesc *desc;      // null for stand-alone launches (t = 0)
+    int     node;              // index of this kernel inside its step (probe slot)
 };
 
 int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s);
+int skinny_kernels_init();
+int launch_step_advance(CallDesc *d, hipStream_t s);
+int launch_set_desc(CallDesc *d, const CallDesc &v, hipStream_t s);
 
 // batched GEMM over all frames: y = act(x @ w^T + bias), M large
 int launch_gemm_batched(const float *x, long long ldx, const float *w, long long ldw, const float *bias,

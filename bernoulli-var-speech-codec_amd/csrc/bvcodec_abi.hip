@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -27,9 +28,19 @@ struct ProbeState {
     std::vector<hipEvent_t> ev;          // pairs
 };
 static ProbeState g_probe;
+static bool g_capturing = false;           // no event probes while a stream is being captured
+
+// in-kernel timestamp probes for the graph-replayed recurrent kernels (wall_clock64, 100 MHz)
+struct KProbe {
+    bool enabled = false;
+    unsigned long long *dev = nullptr;
+    size_t capacity = 0;                   // in u64
+    long long T = 0; int nodes = 0;        // geometry of the last probed call
+};
+static KProbe g_kprobe;
 
 ProbeScope::ProbeScope(int kind, hipStream_t stream) : s(stream), slot(-1) {
-    if (g_probe.kind != kind) return;
+    if (g_probe.kind != kind || g_capturing) return;
     if ((g_probe.counter++ % g_probe.every) != 0) return;
     if ((size_t)(g_probe.used + 1) * 2 > g_probe.ev.size()) return;
     slot = g_probe.used++;
@@ -63,8 +74,15 @@ struct bvc_model {
     std::vector<int> stage_ch;                        // channels after each upsampler
     const float *post_a = nullptr, *post_ib = nullptr, *post_w = nullptr, *post_b = nullptr;
     int post_c = 0, post_ks = 7;
+    // captured recurrent steps (hipGraph), keyed by (kind, batch, workspace)
+    struct StepGraph { int kind; int B; void *ws; hipGraphExec_t exec1, execN; };
+    mutable std::vector<StepGraph> graphs;
+    mutable hipStream_t cap_stream = nullptr;
+    bool use_graph = true;
 
     ~bvc_model() {
+        for (auto &g : graphs) { (void)hipGraphExecDestroy(g.exec1); (void)hipGraphExecDestroy(g.execN); }
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
         for (void *p : allocs) (void)hipFree(p);
     }
 };
@@ -342,7 +360,8 @@ struct Workspace {
     // encode
     float *yn, *pxA, *pxB;
     float *step[16];            // per-step [B, max(H, ...)] scratch vectors
-    float *hA, *hB;
+    float *hbuf;                // [2][B][H] GRU state ping-pong (parity of the frame counter)
+    CallDesc *desc;             // per-call dynamic state read by the captured step kernels
     float *mel, *bits;          // facade-level buffers
     // vocoder
     float *y0, *X, *P, *Q, *U, *XS;
@@ -366,12 +385,14 @@ void carve(const bvc_model *m, int B, int64_t T, char *base, Workspace *w) {
     const size_t BT = (size_t)B * (size_t)T;
     const int H = c.h_dim;
     const int vmax = H > c.num_mels ? H : c.num_mels;
+    // buffers referenced by the captured step graphs come first: their offsets depend on B only, so a
+    // graph captured for (B, workspace) stays valid for every T
+    for (int i = 0; i < 16; ++i) w->step[i] = take((size_t)B * vmax);
+    w->hbuf = take((size_t)2 * B * H);
+    w->desc = reinterpret_cast<CallDesc *>(take(64));
     w->yn = take(BT * c.num_mels);
     w->pxA = take(BT * H);
     w->pxB = take(BT * H);
-    for (int i = 0; i < 16; ++i) w->step[i] = take((size_t)B * vmax);
-    w->hA = take((size_t)B * H);
-    w->hB = take((size_t)B * H);
     w->mel = take(BT * c.num_mels);
     w->bits = take(BT);
     size_t maxel = 0;
@@ -399,71 +420,174 @@ int check_ws(const bvc_model *m, int B, int64_t T, void *d_ws, size_t ws_bytes, 
     return BVC_OK;
 }
 
-GemmParams lin_params(const Linear &l, const float *x, long long ldx, int M, float *y, long long ldy) {
+GemmParams lin_params(const Linear &l, DynPtr x, int M, DynPtr y) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.nseg = 1;
-    p.seg[0] = {x, ldx, l.w, (long long)l.in, l.in, 0};
+    p.seg[0] = GemmSeg{x, l.w, (long long)l.in, l.in, 0};
     p.M = M; p.N = l.out; p.gate_rows = 0;
     p.bias0 = l.b;
-    p.y = y; p.ldy = ldy;
+    p.y = y;
     return p;
 }
 
 // linear over the concatenation [x1 | x2] (torch.cat at bvrnn.py:189,202)
-GemmParams lin2_params(const Linear &l, const float *x1, long long ld1, int K1, const float *x2, long long ld2,
-                       int K2, int M, float *y, long long ldy) {
-    GemmParams p = lin_params(l, x1, ld1, M, y, ldy);
+GemmParams lin2_params(const Linear &l, DynPtr x1, int K1, DynPtr x2, int K2, int M, DynPtr y) {
+    GemmParams p = lin_params(l, x1, M, y);
     p.nseg = 2;
-    p.seg[0] = {x1, ld1, l.w, (long long)l.in, K1, 0};
-    p.seg[1] = {x2, ld2, l.w + K1, (long long)l.in, K2, 0};
+    p.seg[0] = GemmSeg{x1, l.w, (long long)l.in, K1, 0};
+    p.seg[1] = GemmSeg{x2, l.w + K1, (long long)l.in, K2, 0};
     return p;
 }
 
-// phi_z -> dec -> phi_x(normalised dec) -> GRU : the part shared by encode and decode steps
-// (bvrnn.py:198-206 / 223-227).  z = codes of frame t (row stride ldz).
-int step_tail(const bvc_model *m, const Workspace &w, int B, const float *z, long long ldz, const float *h_cur,
-              float *h_next, float *mel_out, long long ldmel, float *h_copy, long long ldhc, hipStream_t s) {
+struct StepNode { GemmParams p; int epi; };
+enum { STEP_ENCODE = 0, STEP_DECODE = 1 };
+
+// The kernel sequence of ONE frame.  Every pointer is either workspace-static, frame-indexed through
+// the call descriptor, or parity-indexed (GRU state), so the same sequence serves every frame and
+// every call: it is captured once into a hipGraph.
+//   encode (bvrnn.py:187-206): enc -> sigmoid/round/mask -> phi_z -> dec -> phi_x(norm) -> GRU
+//   decode (bvrnn.py:222-227): [phi_z batched over all frames beforehand] dec -> phi_x(norm) -> GRU
+std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, int kind) {
     const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
-    int rc;
+    std::vector<StepNode> plan;
+    const long long BH = (long long)B * H;
+    const DynPtr h_cur = dp_parity(w.hbuf, H, BH, 0);
+    const DynPtr h_next = dp_parity(w.hbuf + BH, H, -BH, 0);
+    float *e1 = w.step[0], *e2 = w.step[1];
     float *pz1 = w.step[2], *pz2 = w.step[3], *pz3 = w.step[4];
     float *d1 = w.step[5], *d2 = w.step[6], *d3 = w.step[7], *dn = w.step[8];
     float *g1 = w.step[9], *g2 = w.step[10], *g3 = w.step[11];
-    if ((rc = launch_gemm_skinny(lin_params(m->phi_z[0], z, ldz, B, pz1, H), EPI_ELU, s))) return rc;
-    if ((rc = launch_gemm_skinny(lin_params(m->phi_z[1], pz1, H, B, pz2, H), EPI_ELU, s))) return rc;
-    if ((rc = launch_gemm_skinny(lin_params(m->phi_z[2], pz2, H, B, pz3, H), EPI_ELU, s))) return rc;
-    if ((rc = launch_gemm_skinny(lin2_params(m->dec[0], pz3, H, H, h_cur, H, H, B, d1, H), EPI_ELU, s))) return rc;
-    if ((rc = launch_gemm_skinny(lin_params(m->dec[1], d1, H, B, d2, H), EPI_ELU, s))) return rc;
-    if ((rc = launch_gemm_skinny(lin_params(m->dec[2], d2, H, B, d3, H), EPI_ELU, s))) return rc;
-    {
-        GemmParams p = lin_params(m->dec[3], d3, H, B, mel_out, ldmel);
-        p.y2 = dn; p.ldy2 = X; p.mean = m->mean_mel; p.stdv = m->std_mel;
-        if ((rc = launch_gemm_skinny(p, EPI_MEL, s))) return rc;
+    auto S = [&](float *p, int ld) { return dp_static(p, ld); };
+    DynPtr pz_final;
+    if (kind == STEP_ENCODE) {
+        plan.push_back({lin2_params(m->enc[0], dp_frame(DS_PX, H), H, h_cur, H, B, S(e1, H)), EPI_ELU});
+        plan.push_back({lin_params(m->enc[1], S(e1, H), B, S(e2, H)), EPI_ELU});
+        {
+            GemmParams p = lin_params(m->enc[2], S(e2, H), B, dp_frame(DS_CODES, Z));
+            p.var_bit = m->cfg.var_bit;
+            p.aux = dp_frame(DS_BITS, 1);
+            p.y3 = dp_frame(DS_PROB, Z);
+            plan.push_back({p, EPI_CODE});
+        }
+        plan.push_back({lin_params(m->phi_z[0], dp_frame(DS_CODES, Z), B, S(pz1, H)), EPI_ELU});
+        plan.push_back({lin_params(m->phi_z[1], S(pz1, H), B, S(pz2, H)), EPI_ELU});
+        plan.push_back({lin_params(m->phi_z[2], S(pz2, H), B, S(pz3, H)), EPI_ELU});
+        pz_final = S(pz3, H);
+    } else {
+        pz_final = dp_frame(DS_PZ, H);
     }
-    if ((rc = launch_gemm_skinny(lin_params(m->phi_x[0], dn, X, B, g1, H), EPI_ELU, s))) return rc;
-    if ((rc = launch_gemm_skinny(lin_params(m->phi_x[1], g1, H, B, g2, H), EPI_ELU, s))) return rc;
-    if ((rc = launch_gemm_skinny(lin_params(m->phi_x[2], g2, H, B, g3, H), EPI_ELU, s))) return rc;
+    plan.push_back({lin2_params(m->dec[0], pz_final, H, h_cur, H, B, S(d1, H)), EPI_ELU});
+    plan.push_back({lin_params(m->dec[1], S(d1, H), B, S(d2, H)), EPI_ELU});
+    plan.push_back({lin_params(m->dec[2], S(d2, H), B, S(d3, H)), EPI_ELU});
+    {
+        GemmParams p = lin_params(m->dec[3], S(d3, H), B, kind == STEP_DECODE ? dp_frame(DS_MEL, X) : dp_null());
+        p.y2 = S(dn, X); p.mean = m->mean_mel; p.stdv = m->std_mel;
+        plan.push_back({p, EPI_MEL});
+    }
+    plan.push_back({lin_params(m->phi_x[0], S(dn, X), B, S(g1, H)), EPI_ELU});
+    plan.push_back({lin_params(m->phi_x[1], S(g1, H), B, S(g2, H)), EPI_ELU});
+    plan.push_back({lin_params(m->phi_x[2], S(g2, H), B, S(g3, H)), EPI_ELU});
     {
         GemmParams p;
         memset(&p, 0, sizeof(p));
         p.nseg = 3;
-        p.seg[0] = {g3, (long long)H, m->w_ih, 2LL * H, H, 0};            // cat([phi_x_gen, phi_z]) bvrnn.py:206
-        p.seg[1] = {pz3, (long long)H, m->w_ih + H, 2LL * H, H, 0};
-        p.seg[2] = {h_cur, (long long)H, m->w_hh, (long long)H, H, 1};
+        p.seg[0] = GemmSeg{S(g3, H), m->w_ih, 2LL * H, H, 0};              // cat([phi_x_gen, phi_z]) bvrnn.py:206
+        p.seg[1] = GemmSeg{pz_final, m->w_ih + H, 2LL * H, H, 0};
+        p.seg[2] = GemmSeg{h_cur, m->w_hh, (long long)H, H, 1};
         p.M = B; p.N = H; p.gate_rows = H;
         p.bias0 = m->b_ih; p.bias1 = m->b_hh;
-        p.y = h_next; p.ldy = H;
-        p.y2 = h_copy; p.ldy2 = ldhc;
-        p.aux = h_cur; p.ldaux = H;
-        if ((rc = launch_gemm_skinny(p, EPI_GRU, s))) return rc;
+        p.y = h_next;
+        p.y2 = (kind == STEP_ENCODE) ? dp_frame(DS_ALLH, H, 1) : dp_null();   // all_h[:, t+1] (bvrnn.py:205)
+        p.aux = h_cur;
+        plan.push_back({p, EPI_GRU});
     }
-    (void)Z;
+    for (size_t i = 0; i < plan.size(); ++i) { plan[i].p.desc = w.desc; plan[i].p.node = (int)i; }
+    return plan;
+}
+
+int launch_steps(const std::vector<StepNode> &plan, const Workspace &w, int nsteps, hipStream_t s) {
+    int rc;
+    for (int k = 0; k < nsteps; ++k) {
+        for (const StepNode &n : plan)
+            if ((rc = launch_gemm_skinny(n.p, n.epi, s))) return rc;
+        if ((rc = launch_step_advance(w.desc, s))) return rc;
+    }
     return BVC_OK;
 }
 
-int run_encode(const bvc_model *m, const Workspace &w, const float *d_mel, const float *d_bits, const float *d_h0,
-               int B, int64_t T, float *d_codes, float *d_all_h, float *d_hT, float *d_prob, hipStream_t s) {
-    const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
+constexpr int GRAPH_STEPS = 8;
+
+// Returns the cached graph pair for (kind, B, workspace), capturing it on first use.
+int get_step_graph(const bvc_model *m, const Workspace &w, void *ws_base, int B, int kind,
+                   const std::vector<StepNode> &plan, const bvc_model::StepGraph **out) {
+    for (const auto &g : m->graphs)
+        if (g.kind == kind && g.B == B && g.ws == ws_base) { *out = &g; return BVC_OK; }
+    if (!m->cap_stream) BVC_HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+    bvc_model::StepGraph sg{kind, B, ws_base, nullptr, nullptr};
+    for (int which = 0; which < 2; ++which) {
+        hipGraph_t graph = nullptr;
+        g_capturing = true;
+        hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
+        int rc = BVC_OK;
+        if (e == hipSuccess) rc = launch_steps(plan, w, which ? GRAPH_STEPS : 1, m->cap_stream);
+        hipError_t e2 = (e == hipSuccess) ? hipStreamEndCapture(m->cap_stream, &graph) : e;
+        g_capturing = false;
+        if (rc) return rc;
+        if (e2 != hipSuccess || !graph) { set_error("hipGraph capture failed: %s", hipGetErrorString(e2)); return BVC_EHIP; }
+        hipGraphExec_t ex = nullptr;
+        BVC_HIP_TRY(hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0));
+        BVC_HIP_TRY(hipGraphDestroy(graph));
+        (which ? sg.execN : sg.exec1) = ex;
+    }
+    if (m->graphs.size() >= 16) {               // bound the cache: drop the oldest
+        (void)hipGraphExecDestroy(m->graphs[0].exec1); (void)hipGraphExecDestroy(m->graphs[0].execN);
+        m->graphs.erase(m->graphs.begin());
+    }
+    m->graphs.push_back(sg);
+    *out = &m->graphs.back();
+    return BVC_OK;
+}
+
+int run_recurrence(const bvc_model *m, const Workspace &w, void *ws_base, int B, int64_t T, int kind, hipStream_t s) {
+    const std::vector<StepNode> plan = build_step(m, w, B, kind);
+    int rc;
+    if (!m->use_graph) return launch_steps(plan, w, (int)T, s);
+    const bvc_model::StepGraph *g = nullptr;
+    if ((rc = get_step_graph(m, w, ws_base, B, kind, plan, &g))) return rc;
+    int64_t t = 0;
+    for (; t + GRAPH_STEPS <= T; t += GRAPH_STEPS) BVC_HIP_TRY(hipGraphLaunch(g->execN, s));
+    for (; t < T; ++t) BVC_HIP_TRY(hipGraphLaunch(g->exec1, s));
+    return BVC_OK;
+}
+
+int begin_call(const bvc_model *m, const Workspace &w, const CallDesc &v, int steps_nodes, hipStream_t s) {
+    CallDesc d = v;
+    d.t = 0;
+    d.nodes_per_step = steps_nodes;
+    d.probe = nullptr;
+    if (g_kprobe.enabled) {
+        const size_t need = (size_t)2 * d.T * steps_nodes;
+        if (need <= g_kprobe.capacity) {
+            // first half: start stamps (atomicMin, so all ones); second half: end stamps (atomicMax, so zero)
+            BVC_HIP_TRY(hipMemsetAsync(g_kprobe.dev, 0xFF, need / 2 * sizeof(unsigned long long), s));
+            BVC_HIP_TRY(hipMemsetAsync(g_kprobe.dev + need / 2, 0, need / 2 * sizeof(unsigned long long), s));
+            d.probe = g_kprobe.dev;
+            g_kprobe.T = d.T; g_kprobe.nodes = steps_nodes;
+        }
+    }
+    return launch_set_desc(w.desc, d, s);
+}
+
+int init_state(const Workspace &w, const float *d_h0, int B, int H, hipStream_t s) {
+    if (d_h0) return launch_copy_rows(d_h0, H, w.hbuf, H, B, H, s);
+    return launch_fill(w.hbuf, 0.0f, (long long)B * H, s);
+}
+
+int run_encode(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_mel, const float *d_bits,
+               const float *d_h0, int B, int64_t T, float *d_codes, float *d_all_h, float *d_hT, float *d_prob,
+               hipStream_t s) {
+    const int H = m->cfg.h_dim, X = m->cfg.num_mels;
     const long long BT = (long long)B * T;
     int rc;
     if (m->cfg.var_bit && !d_bits) { set_error("bits per frame required when var_bit=1"); return BVC_EINVAL; }
@@ -472,45 +596,36 @@ int run_encode(const bvc_model *m, const Workspace &w, const float *d_mel, const
     if ((rc = launch_gemm_batched(w.yn, X, m->phi_x[0].w, X, m->phi_x[0].b, (int)BT, H, X, 1, w.pxA, H, s))) return rc;
     if ((rc = launch_gemm_batched(w.pxA, H, m->phi_x[1].w, H, m->phi_x[1].b, (int)BT, H, H, 1, w.pxB, H, s))) return rc;
     if ((rc = launch_gemm_batched(w.pxB, H, m->phi_x[2].w, H, m->phi_x[2].b, (int)BT, H, H, 1, w.pxA, H, s))) return rc;
-    float *h_cur = w.hA, *h_next = w.hB;
-    if (d_h0) { if ((rc = launch_copy_rows(d_h0, H, h_cur, H, B, H, s))) return rc; }
-    else      { if ((rc = launch_fill(h_cur, 0.0f, (long long)B * H, s))) return rc; }
-    if (d_all_h && (rc = launch_copy_rows(h_cur, H, d_all_h, (long long)T * H, B, H, s))) return rc;
-    float *e1 = w.step[0], *e2 = w.step[1];
-    for (int64_t t = 0; t < T; ++t) {
-        // enc(cat[phi_x_t, h]) -> sigmoid -> round -> bit mask  (bvrnn.py:187-194)
-        if ((rc = launch_gemm_skinny(lin2_params(m->enc[0], w.pxA + t * H, (long long)T * H, H, h_cur, H, H, B, e1, H),
-                                     EPI_ELU, s))) return rc;
-        if ((rc = launch_gemm_skinny(lin_params(m->enc[1], e1, H, B, e2, H), EPI_ELU, s))) return rc;
-        {
-            GemmParams p = lin_params(m->enc[2], e2, H, B, d_codes + t * Z, (long long)T * Z);
-            p.var_bit = m->cfg.var_bit;
-            p.aux = d_bits ? d_bits + t : nullptr; p.ldaux = T;
-            if (d_prob) { p.y3 = d_prob + t * Z; p.ldy3 = (long long)T * Z; }
-            if ((rc = launch_gemm_skinny(p, EPI_CODE, s))) return rc;
-        }
-        float *hc = (d_all_h && t + 1 < T) ? d_all_h + (t + 1) * H : nullptr;
-        if ((rc = step_tail(m, w, B, d_codes + t * Z, (long long)T * Z, h_cur, h_next, nullptr, 0, hc,
-                            (long long)T * H, s))) return rc;
-        float *tmp = h_cur; h_cur = h_next; h_next = tmp;
-    }
-    if (d_hT && (rc = launch_copy_rows(h_cur, H, d_hT, H, B, H, s))) return rc;
+    if ((rc = init_state(w, d_h0, B, H, s))) return rc;
+    if (d_all_h && (rc = launch_copy_rows(w.hbuf, H, d_all_h, (long long)T * H, B, H, s))) return rc;
+    CallDesc d;
+    memset(&d, 0, sizeof(d));
+    d.p[DS_PX] = w.pxA; d.p[DS_CODES] = d_codes; d.p[DS_BITS] = const_cast<float *>(d_bits);
+    d.p[DS_PROB] = d_prob; d.p[DS_ALLH] = d_all_h;
+    d.T = T;
+    if ((rc = begin_call(m, w, d, 14, s))) return rc;
+    if ((rc = run_recurrence(m, w, ws_base, B, T, STEP_ENCODE, s))) return rc;
+    if (d_hT && (rc = launch_copy_rows(w.hbuf + (T & 1) * (long long)B * H, H, d_hT, H, B, H, s))) return rc;
     return BVC_OK;
 }
 
-int run_decode(const bvc_model *m, const Workspace &w, const float *d_codes, const float *d_h0, int B, int64_t T,
-               float *d_mel, float *d_hT, hipStream_t s) {
-    const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
+int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_codes, const float *d_h0, int B,
+               int64_t T, float *d_mel, float *d_hT, hipStream_t s) {
+    const int H = m->cfg.h_dim, Z = m->cfg.z_dim;
+    const long long BT = (long long)B * T;
     int rc;
-    float *h_cur = w.hA, *h_next = w.hB;
-    if (d_h0) { if ((rc = launch_copy_rows(d_h0, H, h_cur, H, B, H, s))) return rc; }
-    else      { if ((rc = launch_fill(h_cur, 0.0f, (long long)B * H, s))) return rc; }
-    for (int64_t t = 0; t < T; ++t) {
-        if ((rc = step_tail(m, w, B, d_codes + t * Z, (long long)T * Z, h_cur, h_next, d_mel + t * X,
-                            (long long)T * X, nullptr, 0, s))) return rc;
-        float *tmp = h_cur; h_cur = h_next; h_next = tmp;
-    }
-    if (d_hT && (rc = launch_copy_rows(h_cur, H, d_hT, H, B, H, s))) return rc;
+    // phi_z depends on the codes only: all frames at once, outside the recurrence (bvrnn.py:223)
+    if ((rc = launch_gemm_batched(d_codes, Z, m->phi_z[0].w, Z, m->phi_z[0].b, (int)BT, H, Z, 1, w.pxA, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxA, H, m->phi_z[1].w, H, m->phi_z[1].b, (int)BT, H, H, 1, w.pxB, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxB, H, m->phi_z[2].w, H, m->phi_z[2].b, (int)BT, H, H, 1, w.pxA, H, s))) return rc;
+    if ((rc = init_state(w, d_h0, B, H, s))) return rc;
+    CallDesc d;
+    memset(&d, 0, sizeof(d));
+    d.p[DS_PZ] = w.pxA; d.p[DS_MEL] = d_mel;
+    d.T = T;
+    if ((rc = begin_call(m, w, d, 8, s))) return rc;
+    if ((rc = run_recurrence(m, w, ws_base, B, T, STEP_DECODE, s))) return rc;
+    if (d_hT && (rc = launch_copy_rows(w.hbuf + (T & 1) * (long long)B * H, H, d_hT, H, B, H, s))) return rc;
     return BVC_OK;
 }
 
@@ -587,6 +702,11 @@ int bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t n
     std::unique_ptr<bvc_model> m(new bvc_model());
     m->cfg = *cfg;
     if ((rc = conv_kernels_init())) return rc;
+    if ((rc = skinny_kernels_init())) return rc;
+    {
+        const char *ng = getenv("BVC_NO_GRAPH");
+        m->use_graph = !(ng && ng[0] == '1');
+    }
     if ((rc = build_frontend(m.get(), tm))) return rc;
     if ((rc = build_bvrnn(m.get(), tm))) return rc;
     if ((rc = build_vocoder(m.get(), tm))) return rc;
@@ -632,7 +752,7 @@ int bvc_bvrnn_encode(const bvc_model *m, const float *d_mel, const float *d_bits
     int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
     if (rc) return rc;
     if (!d_mel || !d_codes) { set_error("null argument"); return BVC_EINVAL; }
-    return run_encode(m, w, d_mel, d_bits, d_h0, B, T, d_codes, d_all_h, d_hT, d_prob, (hipStream_t)stream);
+    return run_encode(m, w, d_ws, d_mel, d_bits, d_h0, B, T, d_codes, d_all_h, d_hT, d_prob, (hipStream_t)stream);
 }
 
 int bvc_bvrnn_decode(const bvc_model *m, const float *d_codes, const float *d_h0, int32_t B, int64_t T, float *d_mel,
@@ -641,7 +761,7 @@ int bvc_bvrnn_decode(const bvc_model *m, const float *d_codes, const float *d_h0
     int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
     if (rc) return rc;
     if (!d_codes || !d_mel) { set_error("null argument"); return BVC_EINVAL; }
-    return run_decode(m, w, d_codes, d_h0, B, T, d_mel, d_hT, (hipStream_t)stream);
+    return run_decode(m, w, d_ws, d_codes, d_h0, B, T, d_mel, d_hT, (hipStream_t)stream);
 }
 
 int bvc_bigvgan(const bvc_model *m, const float *d_mel, int32_t B, int64_t T, int64_t length, float out_scale_div,
@@ -666,7 +786,7 @@ int bvc_encode(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, flo
     hipStream_t s = (hipStream_t)stream;
     if ((rc = launch_stft_logmel(m->fe, d_wav, B, L, T, m->cfg.pad_left, scale, w.mel, s))) return rc;
     if ((rc = launch_fill(w.bits, bits_per_frame, (long long)B * T, s))) return rc;
-    return run_encode(m, w, w.mel, w.bits, nullptr, B, T, d_codes, nullptr, nullptr, nullptr, s);
+    return run_encode(m, w, d_ws, w.mel, w.bits, nullptr, B, T, d_codes, nullptr, nullptr, nullptr, s);
 }
 
 int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, int64_t length, float out_scale_div,
@@ -676,7 +796,7 @@ int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, i
     if (rc) return rc;
     if (!d_codes || !d_wav || length <= 0) { set_error("null argument or non-positive length"); return BVC_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = run_decode(m, w, d_codes, nullptr, B, T, w.mel, nullptr, s))) return rc;
+    if ((rc = run_decode(m, w, d_ws, d_codes, nullptr, B, T, w.mel, nullptr, s))) return rc;
     return run_vocoder(m, w, w.mel, B, T, length, out_scale_div, d_wav, -1, nullptr, nullptr, nullptr, s);
 }
 
@@ -710,10 +830,43 @@ int bvc_probe_end(double *mean_us, double *min_us, int32_t *n_samples) {
     return BVC_OK;
 }
 
+int bvc_kprobe_enable(int32_t on) {
+    if (on && !g_kprobe.dev) {
+        const size_t cap = (size_t)2 * 16 * 4096;               // up to 4096 frames x 16 nodes
+        BVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_kprobe.dev), cap * sizeof(unsigned long long)));
+        g_kprobe.capacity = cap;
+    }
+    g_kprobe.enabled = on != 0;
+    return BVC_OK;
+}
+
+int bvc_kprobe_read(int32_t node_lo, int32_t node_hi, double *mean_us, double *min_us, int32_t *n_samples) {
+    BVC_HIP_TRY(hipDeviceSynchronize());
+    double sum = 0.0, mn = 1e30;
+    int n = 0;
+    if (g_kprobe.dev && g_kprobe.T > 0) {
+        const size_t cnt = (size_t)2 * g_kprobe.T * g_kprobe.nodes;
+        std::vector<unsigned long long> h(cnt);
+        BVC_HIP_TRY(hipMemcpy(h.data(), g_kprobe.dev, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (long long t = 0; t < g_kprobe.T; ++t)
+            for (int k = node_lo; k < node_hi && k < g_kprobe.nodes; ++k) {
+                const unsigned long long a = h[t * g_kprobe.nodes + k], b = h[cnt / 2 + t * g_kprobe.nodes + k];
+                if (b <= a) continue;
+                const double us = (double)(b - a) * 0.01;        // 100 MHz ticks
+                sum += us; if (us < mn) mn = us; ++n;
+            }
+    }
+    if (mean_us) *mean_us = n ? sum / n : 0.0;
+    if (min_us) *min_us = n ? mn : 0.0;
+    if (n_samples) *n_samples = n;
+    return BVC_OK;
+}
+
 int bvc_test_linear(const float *d_x, const float *d_w, const float *d_bias, int32_t M, int32_t N, int32_t K,
                     int32_t act, float *d_y, void *stream) {
     Linear l; l.w = d_w; l.b = d_bias; l.in = K; l.out = N;
-    return launch_gemm_skinny(lin_params(l, d_x, K, M, d_y, N), act ? EPI_ELU : EPI_LINEAR, (hipStream_t)stream);
+    return launch_gemm_skinny(lin_params(l, dp_static(d_x, K), M, dp_static(d_y, N)), act ? EPI_ELU : EPI_LINEAR,
+                              (hipStream_t)stream);
 }
 
 int bvc_test_linear_batched(const float *d_x, const float *d_w, const float *d_bias, int32_t M, int32_t N, int32_t K,

@@ -29,14 +29,24 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 __device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : expf(v) - 1.0f; }
 __device__ __forceinline__ float sigmoid1(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+struct Resolved { float *p; long long ld; bool ok; };
+
+__device__ __forceinline__ Resolved resolve(const DynPtr &d, const CallDesc *c, int t, long long T) {
+    if (d.kind == 0) return {d.base, d.ld, d.base != nullptr};
+    if (d.kind == 2) return {d.base + (((t + d.toff) & 1) ? d.poff : 0), d.ld, true};
+    float *b = c->p[d.sel];
+    const long long tt = (long long)t + d.toff;
+    const bool ok = (b != nullptr) && tt >= 0 && tt < T;
+    return {ok ? b + tt * d.dim : nullptr, T * d.dim, ok};
+}
+
 // Accumulate blocks [lo, hi) (16 k each) of one segment into acc[NG].  Rows beyond M read a clamped
 // (valid) row: output row i of an MFMA tile depends only on operand row i, and those rows are never stored.
 template <int NG, int U>
-__device__ __forceinline__ void run_segment(const GemmSeg &s, int lo, int hi, const float *xrow_base,
-                                            bool xvalid, int wrow0, long long gate_rows, int g,
-                                            f32x4 (&acc)[NG]) {
+__device__ __forceinline__ void run_segment(const float *w, long long ldw, int lo, int hi, const float *xrow_base,
+                                            int wrow0, long long gate_rows, int g, f32x4 (&acc)[NG]) {
     const float *xb = xrow_base + (long long)g * 4;
-    const float *wb = s.w + (long long)wrow0 * s.ldw + (long long)g * 4;
+    const float *wb = w + (long long)wrow0 * ldw + (long long)g * 4;
     int kb = lo;
     for (; kb + U <= hi; kb += U) {
         f32x4 xv[U];
@@ -46,7 +56,7 @@ __device__ __forceinline__ void run_segment(const GemmSeg &s, int lo, int hi, co
             xv[u] = *reinterpret_cast<const f32x4 *>(xb + (long long)(kb + u) * 16);
 #pragma unroll
             for (int q = 0; q < NG; ++q)
-                wv[u][q] = *reinterpret_cast<const f32x4 *>(wb + (long long)q * gate_rows * s.ldw +
+                wv[u][q] = *reinterpret_cast<const f32x4 *>(wb + (long long)q * gate_rows * ldw +
                                                             (long long)(kb + u) * 16);
         }
         __builtin_amdgcn_sched_barrier(0);      // keep all U blocks' loads in flight ahead of the MFMAs
@@ -62,7 +72,7 @@ __device__ __forceinline__ void run_segment(const GemmSeg &s, int lo, int hi, co
         f32x4 xv = *reinterpret_cast<const f32x4 *>(xb + (long long)kb * 16);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            f32x4 wv = *reinterpret_cast<const f32x4 *>(wb + (long long)q * gate_rows * s.ldw + (long long)kb * 16);
+            f32x4 wv = *reinterpret_cast<const f32x4 *>(wb + (long long)q * gate_rows * ldw + (long long)kb * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[q] = mfma16(xv[e], wv[e], acc[q]);
         }
@@ -72,6 +82,14 @@ __device__ __forceinline__ void run_segment(const GemmSeg &s, int lo, int hi, co
 template <int NG, int NGRP, int NW, int U>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int epi) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][NGRP*NG][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const CallDesc *dsc = p.desc;
+    const int t = dsc ? dsc->t : 0;
+    const long long T = dsc ? dsc->T : 1;
+    unsigned long long *probe = dsc ? dsc->probe : nullptr;
+    if (probe && tid == 0)       // slots: [0, T*nodes) first-wave start times, [T*nodes, 2*T*nodes) last end times
+        atomicMin(&probe[(long long)t * dsc->nodes_per_step + p.node], (unsigned long long)wall_clock64());
+
     const int n_tiles = p.N >> 4;
     const int m_tiles = (p.M + 15) >> 4;
     const int bid = blockIdx.x;
@@ -80,7 +98,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     const int mtile = slot % m_tiles;
     if (ntile >= n_tiles) return;                                    // uniform per workgroup
     const int m0 = mtile << 4, n0 = ntile << 4;
-    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
 
@@ -94,22 +111,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     for (int s = 0; s < p.nseg; ++s) nb += p.seg[s].K >> 4;
     const int my_lo = (int)(((long long)nb * wave) / NW);
     const int my_hi = (int)(((long long)nb * (wave + 1)) / NW);
-    const bool xvalid = (m0 + r) < p.M;
-    const int xrow = xvalid ? (m0 + r) : (p.M - 1);
+    const int xrow = (m0 + r) < p.M ? (m0 + r) : (p.M - 1);
 
     int base = 0;
     for (int s = 0; s < p.nseg; ++s) {
-        const GemmSeg sg = p.seg[s];
-        const int sb = sg.K >> 4;
+        const int sb = p.seg[s].K >> 4;
         int lo = my_lo - base, hi = my_hi - base;
         lo = lo < 0 ? 0 : lo;
         hi = hi > sb ? sb : hi;
         if (lo < hi) {
-            const float *xrow_base = sg.x + (long long)xrow * sg.ldx;
-            if (NGRP == 1 || sg.grp == 0)
-                run_segment<NG, U>(sg, lo, hi, xrow_base, xvalid, n0 + r, p.gate_rows, g, acc0);
+            const Resolved x = resolve(p.seg[s].x, dsc, t, T);
+            const float *xrow_base = x.p + (long long)xrow * x.ld;
+            if (NGRP == 1 || p.seg[s].grp == 0)
+                run_segment<NG, U>(p.seg[s].w, p.seg[s].ldw, lo, hi, xrow_base, n0 + r, p.gate_rows, g, acc0);
             else
-                run_segment<NG, U>(sg, lo, hi, xrow_base, xvalid, n0 + r, p.gate_rows, g, acc1);
+                run_segment<NG, U>(p.seg[s].w, p.seg[s].ldw, lo, hi, xrow_base, n0 + r, p.gate_rows, g, acc1);
         }
         base += sb;
     }
@@ -136,62 +152,101 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     }
     const int i = tid >> 4, j = tid & 15;
     const int m = m0 + i, n = n0 + j;
-    if (m >= p.M) return;
-
-    if (epi == EPI_LINEAR || epi == EPI_ELU) {
-        float o = v[0] + p.bias0[n];
-        if (epi == EPI_ELU) o = elu1(o);
-        p.y[(long long)m * p.ldy + n] = o;
-    } else if (epi == EPI_CODE) {
-        const float logit = v[0] + p.bias0[n];
-        const float pr = sigmoid1(logit);
-        float z = rintf(pr);                                         // round half to even (torch.round)
-        if (p.var_bit) {
-            const float bits = p.aux[(long long)m * p.ldaux];
-            z = (bits > (float)n) ? z : 0.5f;                        // z*m + 0.5*(1-m)
+    if (m < p.M) {
+        const Resolved y = resolve(p.y, dsc, t, T);
+        if (epi == EPI_LINEAR || epi == EPI_ELU) {
+            float o = v[0] + p.bias0[n];
+            if (epi == EPI_ELU) o = elu1(o);
+            y.p[(long long)m * y.ld + n] = o;
+        } else if (epi == EPI_CODE) {
+            const float logit = v[0] + p.bias0[n];
+            const float pr = sigmoid1(logit);
+            float z = rintf(pr);                                     // round half to even (torch.round)
+            if (p.var_bit) {
+                const Resolved bt = resolve(p.aux, dsc, t, T);
+                const float bits = bt.p[(long long)m * bt.ld];
+                z = (bits > (float)n) ? z : 0.5f;                    // z*m + 0.5*(1-m)
+            }
+            y.p[(long long)m * y.ld + n] = z;
+            const Resolved y3 = resolve(p.y3, dsc, t, T);
+            if (y3.ok) y3.p[(long long)m * y3.ld + n] = pr;
+        } else if (epi == EPI_MEL) {
+            const float d = v[0] + p.bias0[n];
+            if (y.ok) y.p[(long long)m * y.ld + n] = d;
+            const Resolved y2 = resolve(p.y2, dsc, t, T);
+            y2.p[(long long)m * y2.ld + n] = (d - p.mean[n]) / p.stdv[n];
+        } else if (NGRP > 1 && NG == 3) {                            // EPI_GRU
+            const long long H = p.gate_rows;
+            const float gi_r = v[0] + p.bias0[n], gi_z = v[1] + p.bias0[H + n], gi_n = v[2] + p.bias0[2 * H + n];
+            const float gh_r = v[NACC > 3 ? 3 : 0] + p.bias1[n];
+            const float gh_z = v[NACC > 4 ? 4 : 0] + p.bias1[H + n];
+            const float gh_n = v[NACC > 5 ? 5 : 0] + p.bias1[2 * H + n];
+            const float rg = sigmoid1(gh_r + gi_r);
+            const float zg = sigmoid1(gh_z + gi_z);
+            const float ng = tanhf(gi_n + rg * gh_n);
+            const Resolved hprev = resolve(p.aux, dsc, t, T);
+            const float hp = hprev.p[(long long)m * hprev.ld + n];
+            const float hn = (hp - ng) * zg + ng;
+            y.p[(long long)m * y.ld + n] = hn;
+            const Resolved y2 = resolve(p.y2, dsc, t, T);
+            if (y2.ok) y2.p[(long long)m * y2.ld + n] = hn;
         }
-        p.y[(long long)m * p.ldy + n] = z;
-        if (p.y3) p.y3[(long long)m * p.ldy3 + n] = pr;
-    } else if (epi == EPI_MEL) {
-        const float d = v[0] + p.bias0[n];
-        if (p.y) p.y[(long long)m * p.ldy + n] = d;
-        p.y2[(long long)m * p.ldy2 + n] = (d - p.mean[n]) / p.stdv[n];
-    } else if (NGRP > 1 && NG == 3) {                                // EPI_GRU
-        const long long H = p.gate_rows;
-        const float gi_r = v[0] + p.bias0[n], gi_z = v[1] + p.bias0[H + n], gi_n = v[2] + p.bias0[2 * H + n];
-        const float gh_r = v[NACC > 3 ? 3 : 0] + p.bias1[n];
-        const float gh_z = v[NACC > 4 ? 4 : 0] + p.bias1[H + n];
-        const float gh_n = v[NACC > 5 ? 5 : 0] + p.bias1[2 * H + n];
-        const float rg = sigmoid1(gh_r + gi_r);
-        const float zg = sigmoid1(gh_z + gi_z);
-        const float ng = tanhf(gi_n + rg * gh_n);
-        const float hp = p.aux[(long long)m * p.ldaux + n];
-        const float hn = (hp - ng) * zg + ng;
-        p.y[(long long)m * p.ldy + n] = hn;
-        if (p.y2) p.y2[(long long)m * p.ldy2 + n] = hn;
     }
+    if (probe && tid == 0)
+        atomicMax(&probe[(T + t) * dsc->nodes_per_step + p.node], (unsigned long long)wall_clock64());
+}
+
+template <int NG, int NGRP, int NW, int U>
+static void launch_skinny_t(const GemmParams &p, int epi, int grid, hipStream_t s) {
+    const size_t lds = (size_t)NW * NG * NGRP * 256 * sizeof(float);
+    hipLaunchKernelGGL((gemm_skinny_kernel<NG, NGRP, NW, U>), dim3(grid), dim3(NW * 64), lds, s, p, epi);
+}
+
+int skinny_kernels_init() {
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_kernel<3, 2, 16, 3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 6 * 1024));
+    return BVC_OK;
 }
 
 int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s) {
     if (p.M <= 0) return BVC_OK;
     if (p.N % 16) { set_error("gemm_skinny: N=%d not a multiple of 16", p.N); return BVC_EINVAL; }
-    for (int i = 0; i < p.nseg; ++i)
-        if (p.seg[i].K % 16 || p.seg[i].ldx % 4 || p.seg[i].ldw % 4) {
-            set_error("gemm_skinny: segment %d K=%d ldx=%lld ldw=%lld must be multiples of 16/4/4", i,
-                      p.seg[i].K, p.seg[i].ldx, p.seg[i].ldw);
+    int nb = 0;
+    for (int i = 0; i < p.nseg; ++i) {
+        if (p.seg[i].K % 16 || p.seg[i].ldw % 4 || (p.seg[i].x.kind != 1 && p.seg[i].x.ld % 4) ||
+            (p.seg[i].x.kind == 1 && p.seg[i].x.dim % 4)) {
+            set_error("gemm_skinny: segment %d K=%d ldw=%lld: K must be a multiple of 16, strides of 4", i,
+                      p.seg[i].K, p.seg[i].ldw);
             return BVC_EINVAL;
         }
+        nb += p.seg[i].K / 16;
+    }
     const int n_tiles = p.N / 16, m_tiles = (p.M + 15) / 16;
     const int grid = 8 * ((n_tiles + 7) / 8) * m_tiles;
-    constexpr int NW = 8;
     ProbeScope probe(epi == EPI_GRU ? PK_GRU : PK_LINEAR, s);
-    if (epi == EPI_GRU) {
-        const size_t lds = (size_t)NW * 6 * 256 * sizeof(float);
-        hipLaunchKernelGGL((gemm_skinny_kernel<3, 2, NW, 4>), dim3(grid), dim3(NW * 64), lds, s, p, epi);
-    } else {
-        const size_t lds = (size_t)NW * 1 * 256 * sizeof(float);
-        hipLaunchKernelGGL((gemm_skinny_kernel<1, 1, NW, 8>), dim3(grid), dim3(NW * 64), lds, s, p, epi);
-    }
+    if (epi == EPI_GRU)      launch_skinny_t<3, 2, 16, 3>(p, epi, grid, s);
+    else if (nb >= 128)      launch_skinny_t<1, 1, 16, 8>(p, epi, grid, s);
+    else                     launch_skinny_t<1, 1, 8, 8>(p, epi, grid, s);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
+__global__ void step_advance_kernel(CallDesc *d) {
+    if (threadIdx.x == 0) d->t = d->t + 1;
+}
+
+int launch_step_advance(CallDesc *d, hipStream_t s) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, d);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
+__global__ void set_desc_kernel(CallDesc *d, CallDesc v) {
+    if (threadIdx.x == 0) *d = v;
+}
+
+int launch_set_desc(CallDesc *d, const CallDesc &v, hipStream_t s) {
+    hipLaunchKernelGGL(set_desc_kernel, dim3(1), dim3(64), 0, s, d, v);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }

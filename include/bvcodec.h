@@ -145,6 +145,14 @@ int bvc_test_vocoder_tap(const bvc_model *m, const float *d_mel, int32_t B, int6
  * the mean / min elapsed microseconds.  Not thread-safe; off by default. */
 int bvc_probe_begin(int32_t kind, int32_t sample_every, int32_t max_samples);
 int bvc_probe_end(double *mean_us, double *min_us, int32_t *n_samples);
+/* The recurrent BVRNN kernels are replayed from a hipGraph, where event pairs cannot be inserted:
+ * with bvc_kprobe_enable(1) every workgroup of those kernels stamps wall_clock64() (100 MHz) at its
+ * start and end into a device buffer; bvc_kprobe_read returns the mean/min kernel duration
+ * (first workgroup start -> last workgroup end) over all frames of the LAST bvrnn encode/decode call
+ * for the step-kernel indices [node_lo, node_hi).  Encode step: 0 enc.0, 1 enc.2, 2 enc.4(+sigmoid/
+ * round/mask), 3-5 phi_z, 6-9 dec, 10-12 phi_x, 13 GRU.  Decode step: 0-3 dec, 4-6 phi_x, 7 GRU. */
+int bvc_kprobe_enable(int32_t on);
+int bvc_kprobe_read(int32_t node_lo, int32_t node_hi, double *mean_us, double *min_us, int32_t *n_samples);
 
 #ifdef __cplusplus
 }

@@ -145,6 +145,40 @@ def timing():
     print("finite", bool(torch.isfinite(wav).all()), "wav rms", float(wav.pow(2).mean().sqrt()))
 
 
+
+def kprobe():
+    """Per-layer in-kernel durations of the graph-replayed recurrent kernels at the C2 shape."""
+    lib = _abi.load()
+    model = make_model()[0]
+    x = synth.synthetic_speech(64, 110250, seed=0, kind="noise").to(DEV)
+    codes = model.encode(x, 3000)
+    _abi.check(lib.bvc_kprobe_enable(1))
+    enc_names = ["enc.0 K2048", "enc.2", "enc.4 N64", "phi_z.0 K64", "phi_z.2", "phi_z.4", "dec.0 K2048", "dec.2",
+                 "dec.4", "dec.6 N80", "phi_x.0 K80", "phi_x.2", "phi_x.4", "GRU"]
+    dec_names = enc_names[6:]
+
+    def dump(names):
+        tot = 0.0
+        for k, nm in enumerate(names):
+            mean, mn, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
+            _abi.check(lib.bvc_kprobe_read(k, k + 1, ctypes.byref(mean), ctypes.byref(mn), ctypes.byref(n)))
+            print(f"   node {k:2d} {nm:14s} mean {mean.value:7.2f} us  min {mn.value:7.2f} us  n {n.value}")
+            tot += mean.value
+        print(f"   sum of kernel bodies per step: {tot:.1f} us")
+
+    torch.cuda.synchronize(); t0 = time.time()
+    codes = model.encode(x, 3000)
+    torch.cuda.synchronize(); t1 = time.time()
+    print(f"encode (probed) {1e3 * (t1 - t0):.1f} ms -> {1e6 * (t1 - t0) / 430:.1f} us per step wall")
+    dump(enc_names)
+    torch.cuda.synchronize(); t0 = time.time()
+    model.decode(codes, 110250)
+    torch.cuda.synchronize(); t1 = time.time()
+    print(f"decode (probed, incl. vocoder) {1e3 * (t1 - t0):.1f} ms")
+    dump(dec_names)
+    _abi.check(lib.bvc_kprobe_enable(0))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "frontend", "bvrnn", "vocoder", "facade", "timing"]
     for w in which:
