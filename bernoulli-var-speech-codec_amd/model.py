@@ -72,7 +72,7 @@ class _Engine:
         with torch.cuda.device(device):
             _abi.check(self.lib.bvc_model_create(ctypes.byref(cfg), arr, len(names), ctypes.byref(handle)))
         self.handle = handle
-        self._ws = None
+        self._ws = {}            # one workspace per stream: calls on different streams may overlap
 
     def __del__(self):
         try:
@@ -83,11 +83,15 @@ class _Engine:
             pass
 
     def workspace(self, B, T):
+        """Scratch for one call, owned by the CURRENT stream (the C ABI allows one in-flight call per
+        (model, workspace); independent batches issued on different streams therefore overlap)."""
         need = self.lib.bvc_workspace_bytes(self.handle, B, T)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return ctypes.c_void_p(self._ws.data_ptr()), self._ws.numel()
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws[key] = None
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ctypes.c_void_p(ws.data_ptr()), ws.numel()
 
     def stream(self):
         return _abi.current_stream(self.device)
