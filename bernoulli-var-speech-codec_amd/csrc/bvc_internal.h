@@ -48,22 +48,28 @@ struct CallDesc {
 //   kind 0 (static) : base, row stride ld
 //   kind 1 (frame)  : desc->p[sel] + (t + toff) * dim, row stride T * dim; invalid outside [0, T) or if null
 //   kind 2 (parity) : base + (((t + toff) & 1) ? poff : 0), row stride ld      (GRU state ping-pong)
+//   packed != 0: the [M][ld] matrix is stored in MFMA A-operand fragment order
+//       [m/16][k/16][lane = ((k%16)/4)*16 + m%16][k%4]   (one 16x16 block = 1 KiB contiguous),
+//       so a wave's operand load is one fully coalesced 1 KiB read; frame tensors then hold one such
+//       packed [M][dim] matrix per frame.
 struct DynPtr {
     float *base;
     long long ld;
     long long poff;
     int kind, sel, dim, toff;
+    int packed;
 };
-inline DynPtr dp_static(const float *p, long long ld) { return DynPtr{const_cast<float *>(p), ld, 0, 0, 0, 0, 0}; }
-inline DynPtr dp_frame(int sel, int dim, int toff = 0) { return DynPtr{nullptr, 0, 0, 1, sel, dim, toff}; }
-inline DynPtr dp_parity(float *p, long long ld, long long poff, int flip) { return DynPtr{p, ld, poff, 2, 0, 0, flip}; }
-inline DynPtr dp_null() { return DynPtr{nullptr, 0, 0, 0, 0, 0, 0}; }
+inline DynPtr dp_static(const float *p, long long ld, int packed = 0) { return DynPtr{const_cast<float *>(p), ld, 0, 0, 0, 0, 0, packed}; }
+inline DynPtr dp_frame(int sel, int dim, int toff = 0, int packed = 0) { return DynPtr{nullptr, 0, 0, 1, sel, dim, toff, packed}; }
+inline DynPtr dp_parity(float *p, long long ld, long long poff, int flip, int packed = 0) { return DynPtr{p, ld, poff, 2, 0, 0, flip, packed}; }
+inline DynPtr dp_null() { return DynPtr{nullptr, 0, 0, 0, 0, 0, 0, 0}; }
 
 // One K-segment of a (possibly concatenated) input:  acc[grp] += x[M,K] @ w[rows,K]^T
 struct GemmSeg {
     DynPtr       x;      // [M][ld]
-    const float *w;      // [rows][ldw], row = gate*gate_rows + n
-    long long    ldw;
+    const float *w;      // weights in MFMA B-operand fragment order [n/16][k/16][lane][4], already offset
+                         // to this segment's first k-block
+    int          wnb;    // k-blocks (of 16) per weight row, i.e. floats between n-tiles / 256
     int          K;      // multiple of 16
     int          grp;    // accumulator group (0: input part, 1: hidden part of the GRU)
 };
@@ -80,7 +86,7 @@ struct GemmParams {
     GemmSeg seg[3];
     int     nseg;
     int     M, N;              // N = outputs per gate (multiple of 16)
-    long long gate_rows;       // row distance between gates inside w (GRU: h_dim)
+    long long gate_rows;       // row distance between gates inside w (GRU: h_dim); bias index stride
     const float *bias0;        // group 0 bias [gates*N]
     const float *bias1;        // group 1 bias (GRU only)
     DynPtr  y, y2, y3;         // outputs (y2/y3 optional)
@@ -97,13 +103,17 @@ int launch_step_advance(CallDesc *d, hipStream_t s);
 int launch_set_desc(CallDesc *d, const CallDesc &v, hipStream_t s);
 
 // batched GEMM over all frames: y = act(x @ w^T + bias), M large
+// frames_T > 0: rows are (b, t) pairs, b = row / frames_T, and y is written frame-packed:
+// frame t holds the fragment-packed [B][N] matrix at y + t * ceil(B/16)*16 * N.
 int launch_gemm_batched(const float *x, long long ldx, const float *w, long long ldw, const float *bias,
-                        int M, int N, int K, int act, float *y, long long ldy, hipStream_t s);
+                        int M, int N, int K, int act, float *y, long long ldy, hipStream_t s, long long frames_T = 0);
 // yn = (y - mean) / std over rows of length n (bvrnn.py:173)
 int launch_normalize_rows(const float *y, const float *mean, const float *stdv, long long rows, int n,
                           float *out, hipStream_t s);
 int launch_fill(float *p, float v, long long n, hipStream_t s);
 int launch_copy_rows(const float *src, long long lds, float *dst, long long ldd, int rows, int n, hipStream_t s);
+// natural [rows][n] (row stride ld) <-> fragment-packed [rows/16][n/16][64][4]; dir 0: pack, 1: unpack
+int launch_repack_rows(const float *src, float *dst, long long ld_natural, int rows, int n, int dir, hipStream_t s);
 
 // ------------------------------------------------------------------ front-end (k_frontend.hip)
 struct FrontendTables {          // device pointers

@@ -50,7 +50,7 @@ ProbeScope::~ProbeScope() {
     if (slot >= 0) (void)hipEventRecord(g_probe.ev[2 * slot + 1], s);
 }
 
-struct Linear { const float *w = nullptr, *b = nullptr; int in = 0, out = 0; };
+struct Linear { const float *w = nullptr, *wp = nullptr, *b = nullptr; int in = 0, out = 0; };   // w natural, wp fragment-packed
 
 struct AmpPair { ConvLayer c1, c2; };
 
@@ -66,7 +66,7 @@ struct bvc_model {
     // BVRNN
     const float *mean_mel = nullptr, *std_mel = nullptr;
     Linear phi_x[3], phi_z[3], enc[3], dec[4];
-    const float *w_ih = nullptr, *w_hh = nullptr, *b_ih = nullptr, *b_hh = nullptr;
+    const float *w_ih = nullptr, *w_hh = nullptr, *b_ih = nullptr, *b_hh = nullptr;     // w_*: fragment-packed
     // vocoder
     ConvLayer conv_pre;
     std::vector<ConvLayer> ups;                       // n_up
@@ -122,6 +122,17 @@ const bvc_tensor *find(const TensorMap &tm, const std::string &name, int64_t num
     return it->second;
 }
 
+// Linear weight W[N][K] (row-major) -> MFMA B-operand fragment order [N/16][K/16][lane][4]:
+// lane = ((k%16)/4)*16 + n%16 holds W[n][k..k+3]; one (n-tile, k-block) pair is 1 KiB contiguous.
+std::vector<float> pack_linear(const float *W, int N, int K) {
+    std::vector<float> p((size_t)N * K);
+    const int nb = K / 16;
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k)
+            p[((((size_t)(n >> 4) * nb + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + (n & 15)) << 2) + (k & 3)] = W[(size_t)n * K + k];
+    return p;
+}
+
 int load_linear(bvc_model *m, const TensorMap &tm, const std::string &name, int in, int out, Linear *l) {
     const bvc_tensor *w = find(tm, name + ".weight", (int64_t)in * out);
     if (!w) return BVC_EMISSING;
@@ -129,7 +140,8 @@ int load_linear(bvc_model *m, const TensorMap &tm, const std::string &name, int 
     if (!b) return BVC_EMISSING;
     l->in = in; l->out = out;
     int rc;
-    if ((rc = upload_raw(m, w->h_data, w->numel, &l->w))) return rc;
+    if ((rc = upload_raw(m, w->h_data, w->numel, &l->w))) return rc;          // natural: batched GEMM
+    if ((rc = upload(m, pack_linear(w->h_data, out, in), &l->wp))) return rc;  // packed: recurrent kernels
     return upload_raw(m, b->h_data, b->numel, &l->b);
 }
 
@@ -261,9 +273,9 @@ int build_bvrnn(bvc_model *m, const TensorMap &tm) {
     for (int i = 0; i < 4; ++i)
         if ((rc = load_linear(m, tm, "dec." + std::to_string(2 * i), de_in[i], de_out[i], &m->dec[i]))) return rc;
     if (!(t = find(tm, "rnn.weight_ih_l0", (int64_t)3 * H * 2 * H))) return BVC_EMISSING;
-    if ((rc = upload_raw(m, t->h_data, t->numel, &m->w_ih))) return rc;
+    if ((rc = upload(m, pack_linear(t->h_data, 3 * H, 2 * H), &m->w_ih))) return rc;
     if (!(t = find(tm, "rnn.weight_hh_l0", (int64_t)3 * H * H))) return BVC_EMISSING;
-    if ((rc = upload_raw(m, t->h_data, t->numel, &m->w_hh))) return rc;
+    if ((rc = upload(m, pack_linear(t->h_data, 3 * H, H), &m->w_hh))) return rc;
     if (!(t = find(tm, "rnn.bias_ih_l0", 3 * H))) return BVC_EMISSING;
     if ((rc = upload_raw(m, t->h_data, t->numel, &m->b_ih))) return rc;
     if (!(t = find(tm, "rnn.bias_hh_l0", 3 * H))) return BVC_EMISSING;
@@ -358,7 +370,7 @@ inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 // ---- workspace layout ---------------------------------------------------------------------------
 struct Workspace {
     // encode
-    float *yn, *pxA, *pxB;
+    float *yn, *pxA, *pxB, *pxC;
     float *step[16];            // per-step [B, max(H, ...)] scratch vectors
     float *hbuf;                // [2][B][H] GRU state ping-pong (parity of the frame counter)
     CallDesc *desc;             // per-call dynamic state read by the captured step kernels
@@ -385,14 +397,16 @@ void carve(const bvc_model *m, int B, int64_t T, char *base, Workspace *w) {
     const size_t BT = (size_t)B * (size_t)T;
     const int H = c.h_dim;
     const int vmax = H > c.num_mels ? H : c.num_mels;
+    const size_t mt16 = (size_t)((B + 15) / 16) * 16;          // fragment-packed matrices hold whole 16-row tiles
     // buffers referenced by the captured step graphs come first: their offsets depend on B only, so a
     // graph captured for (B, workspace) stays valid for every T
-    for (int i = 0; i < 16; ++i) w->step[i] = take((size_t)B * vmax);
-    w->hbuf = take((size_t)2 * B * H);
+    for (int i = 0; i < 16; ++i) w->step[i] = take(mt16 * vmax);
+    w->hbuf = take(2 * mt16 * H);
     w->desc = reinterpret_cast<CallDesc *>(take(64));
     w->yn = take(BT * c.num_mels);
-    w->pxA = take(BT * H);
+    w->pxA = take(mt16 * (size_t)T * H);                       // final phi_x / phi_z: frame-packed
     w->pxB = take(BT * H);
+    w->pxC = take(BT * H);
     w->mel = take(BT * c.num_mels);
     w->bits = take(BT);
     size_t maxel = 0;
@@ -424,7 +438,7 @@ GemmParams lin_params(const Linear &l, DynPtr x, int M, DynPtr y) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.nseg = 1;
-    p.seg[0] = GemmSeg{x, l.w, (long long)l.in, l.in, 0};
+    p.seg[0] = GemmSeg{x, l.wp, l.in / 16, l.in, 0};
     p.M = M; p.N = l.out; p.gate_rows = 0;
     p.bias0 = l.b;
     p.y = y;
@@ -435,8 +449,8 @@ GemmParams lin_params(const Linear &l, DynPtr x, int M, DynPtr y) {
 GemmParams lin2_params(const Linear &l, DynPtr x1, int K1, DynPtr x2, int K2, int M, DynPtr y) {
     GemmParams p = lin_params(l, x1, M, y);
     p.nseg = 2;
-    p.seg[0] = GemmSeg{x1, l.w, (long long)l.in, K1, 0};
-    p.seg[1] = GemmSeg{x2, l.w + K1, (long long)l.in, K2, 0};
+    p.seg[0] = GemmSeg{x1, l.wp, l.in / 16, K1, 0};
+    p.seg[1] = GemmSeg{x2, l.wp + (size_t)(K1 / 16) * 256, l.in / 16, K2, 0};
     return p;
 }
 
@@ -445,23 +459,24 @@ enum { STEP_ENCODE = 0, STEP_DECODE = 1 };
 
 // The kernel sequence of ONE frame.  Every pointer is either workspace-static, frame-indexed through
 // the call descriptor, or parity-indexed (GRU state), so the same sequence serves every frame and
-// every call: it is captured once into a hipGraph.
+// every call: it is captured once into a hipGraph.  Internal activations are kept in MFMA fragment
+// order (packed=1) so every operand load is a coalesced 1 KiB read.
 //   encode (bvrnn.py:187-206): enc -> sigmoid/round/mask -> phi_z -> dec -> phi_x(norm) -> GRU
 //   decode (bvrnn.py:222-227): [phi_z batched over all frames beforehand] dec -> phi_x(norm) -> GRU
 std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, int kind) {
     const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
     std::vector<StepNode> plan;
-    const long long BH = (long long)B * H;
-    const DynPtr h_cur = dp_parity(w.hbuf, H, BH, 0);
-    const DynPtr h_next = dp_parity(w.hbuf + BH, H, -BH, 0);
+    const long long MH = (long long)((B + 15) / 16) * 16 * H;
+    const DynPtr h_cur = dp_parity(w.hbuf, H, MH, 0, 1);
+    const DynPtr h_next = dp_parity(w.hbuf + MH, H, -MH, 0, 1);
     float *e1 = w.step[0], *e2 = w.step[1];
     float *pz1 = w.step[2], *pz2 = w.step[3], *pz3 = w.step[4];
     float *d1 = w.step[5], *d2 = w.step[6], *d3 = w.step[7], *dn = w.step[8];
     float *g1 = w.step[9], *g2 = w.step[10], *g3 = w.step[11];
-    auto S = [&](float *p, int ld) { return dp_static(p, ld); };
+    auto S = [&](float *p, int ld) { return dp_static(p, ld, 1); };
     DynPtr pz_final;
     if (kind == STEP_ENCODE) {
-        plan.push_back({lin2_params(m->enc[0], dp_frame(DS_PX, H), H, h_cur, H, B, S(e1, H)), EPI_ELU});
+        plan.push_back({lin2_params(m->enc[0], dp_frame(DS_PX, H, 0, 1), H, h_cur, H, B, S(e1, H)), EPI_ELU});
         plan.push_back({lin_params(m->enc[1], S(e1, H), B, S(e2, H)), EPI_ELU});
         {
             GemmParams p = lin_params(m->enc[2], S(e2, H), B, dp_frame(DS_CODES, Z));
@@ -475,7 +490,7 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
         plan.push_back({lin_params(m->phi_z[2], S(pz2, H), B, S(pz3, H)), EPI_ELU});
         pz_final = S(pz3, H);
     } else {
-        pz_final = dp_frame(DS_PZ, H);
+        pz_final = dp_frame(DS_PZ, H, 0, 1);
     }
     plan.push_back({lin2_params(m->dec[0], pz_final, H, h_cur, H, B, S(d1, H)), EPI_ELU});
     plan.push_back({lin_params(m->dec[1], S(d1, H), B, S(d2, H)), EPI_ELU});
@@ -492,9 +507,9 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
         GemmParams p;
         memset(&p, 0, sizeof(p));
         p.nseg = 3;
-        p.seg[0] = GemmSeg{S(g3, H), m->w_ih, 2LL * H, H, 0};              // cat([phi_x_gen, phi_z]) bvrnn.py:206
-        p.seg[1] = GemmSeg{pz_final, m->w_ih + H, 2LL * H, H, 0};
-        p.seg[2] = GemmSeg{h_cur, m->w_hh, (long long)H, H, 1};
+        p.seg[0] = GemmSeg{S(g3, H), m->w_ih, 2 * H / 16, H, 0};                       // cat([phi_x_gen, phi_z]) bvrnn.py:206
+        p.seg[1] = GemmSeg{pz_final, m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0};
+        p.seg[2] = GemmSeg{h_cur, m->w_hh, H / 16, H, 1};
         p.M = B; p.N = H; p.gate_rows = H;
         p.bias0 = m->b_ih; p.bias1 = m->b_hh;
         p.y = h_next;
@@ -579,9 +594,15 @@ int begin_call(const bvc_model *m, const Workspace &w, const CallDesc &v, int st
     return launch_set_desc(w.desc, d, s);
 }
 
+// GRU state lives fragment-packed in hbuf[parity]; h0 goes to parity 0
 int init_state(const Workspace &w, const float *d_h0, int B, int H, hipStream_t s) {
-    if (d_h0) return launch_copy_rows(d_h0, H, w.hbuf, H, B, H, s);
-    return launch_fill(w.hbuf, 0.0f, (long long)B * H, s);
+    if (d_h0) return launch_repack_rows(d_h0, w.hbuf, H, B, H, 0, s);
+    return launch_fill(w.hbuf, 0.0f, (long long)((B + 15) / 16) * 16 * H, s);
+}
+
+int read_state(const Workspace &w, int B, int H, int64_t T, float *d_hT, hipStream_t s) {
+    const float *src = w.hbuf + (T & 1) * (long long)((B + 15) / 16) * 16 * H;
+    return launch_repack_rows(src, d_hT, H, B, H, 1, s);
 }
 
 int run_encode(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_mel, const float *d_bits,
@@ -593,11 +614,11 @@ int run_encode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     if (m->cfg.var_bit && !d_bits) { set_error("bits per frame required when var_bit=1"); return BVC_EINVAL; }
     // y = (y - mean) / std ; phi_x over all frames (bvrnn.py:173-178)
     if ((rc = launch_normalize_rows(d_mel, m->mean_mel, m->std_mel, BT, X, w.yn, s))) return rc;
-    if ((rc = launch_gemm_batched(w.yn, X, m->phi_x[0].w, X, m->phi_x[0].b, (int)BT, H, X, 1, w.pxA, H, s))) return rc;
-    if ((rc = launch_gemm_batched(w.pxA, H, m->phi_x[1].w, H, m->phi_x[1].b, (int)BT, H, H, 1, w.pxB, H, s))) return rc;
-    if ((rc = launch_gemm_batched(w.pxB, H, m->phi_x[2].w, H, m->phi_x[2].b, (int)BT, H, H, 1, w.pxA, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.yn, X, m->phi_x[0].w, X, m->phi_x[0].b, (int)BT, H, X, 1, w.pxC, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxC, H, m->phi_x[1].w, H, m->phi_x[1].b, (int)BT, H, H, 1, w.pxB, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxB, H, m->phi_x[2].w, H, m->phi_x[2].b, (int)BT, H, H, 1, w.pxA, H, s, T))) return rc;
     if ((rc = init_state(w, d_h0, B, H, s))) return rc;
-    if (d_all_h && (rc = launch_copy_rows(w.hbuf, H, d_all_h, (long long)T * H, B, H, s))) return rc;
+    if (d_all_h && (rc = launch_repack_rows(w.hbuf, d_all_h, (long long)T * H, B, H, 1, s))) return rc;
     CallDesc d;
     memset(&d, 0, sizeof(d));
     d.p[DS_PX] = w.pxA; d.p[DS_CODES] = d_codes; d.p[DS_BITS] = const_cast<float *>(d_bits);
@@ -605,7 +626,7 @@ int run_encode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     d.T = T;
     if ((rc = begin_call(m, w, d, 14, s))) return rc;
     if ((rc = run_recurrence(m, w, ws_base, B, T, STEP_ENCODE, s))) return rc;
-    if (d_hT && (rc = launch_copy_rows(w.hbuf + (T & 1) * (long long)B * H, H, d_hT, H, B, H, s))) return rc;
+    if (d_hT && (rc = read_state(w, B, H, T, d_hT, s))) return rc;
     return BVC_OK;
 }
 
@@ -615,9 +636,9 @@ int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     const long long BT = (long long)B * T;
     int rc;
     // phi_z depends on the codes only: all frames at once, outside the recurrence (bvrnn.py:223)
-    if ((rc = launch_gemm_batched(d_codes, Z, m->phi_z[0].w, Z, m->phi_z[0].b, (int)BT, H, Z, 1, w.pxA, H, s))) return rc;
-    if ((rc = launch_gemm_batched(w.pxA, H, m->phi_z[1].w, H, m->phi_z[1].b, (int)BT, H, H, 1, w.pxB, H, s))) return rc;
-    if ((rc = launch_gemm_batched(w.pxB, H, m->phi_z[2].w, H, m->phi_z[2].b, (int)BT, H, H, 1, w.pxA, H, s))) return rc;
+    if ((rc = launch_gemm_batched(d_codes, Z, m->phi_z[0].w, Z, m->phi_z[0].b, (int)BT, H, Z, 1, w.pxC, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxC, H, m->phi_z[1].w, H, m->phi_z[1].b, (int)BT, H, H, 1, w.pxB, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxB, H, m->phi_z[2].w, H, m->phi_z[2].b, (int)BT, H, H, 1, w.pxA, H, s, T))) return rc;
     if ((rc = init_state(w, d_h0, B, H, s))) return rc;
     CallDesc d;
     memset(&d, 0, sizeof(d));
@@ -625,7 +646,7 @@ int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     d.T = T;
     if ((rc = begin_call(m, w, d, 8, s))) return rc;
     if ((rc = run_recurrence(m, w, ws_base, B, T, STEP_DECODE, s))) return rc;
-    if (d_hT && (rc = launch_copy_rows(w.hbuf + (T & 1) * (long long)B * H, H, d_hT, H, B, H, s))) return rc;
+    if (d_hT && (rc = read_state(w, B, H, T, d_hT, s))) return rc;
     return BVC_OK;
 }
 
@@ -864,9 +885,19 @@ int bvc_kprobe_read(int32_t node_lo, int32_t node_hi, double *mean_us, double *m
 
 int bvc_test_linear(const float *d_x, const float *d_w, const float *d_bias, int32_t M, int32_t N, int32_t K,
                     int32_t act, float *d_y, void *stream) {
-    Linear l; l.w = d_w; l.b = d_bias; l.in = K; l.out = N;
-    return launch_gemm_skinny(lin_params(l, dp_static(d_x, K), M, dp_static(d_y, N)), act ? EPI_ELU : EPI_LINEAR,
-                              (hipStream_t)stream);
+    // test helper (allocates + synchronises): packs the natural weight on the device first
+    if (K % 16 || N % 16) { set_error("bvc_test_linear: N and K must be multiples of 16"); return BVC_EINVAL; }
+    float *wp = nullptr;
+    BVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&wp), (size_t)N * K * sizeof(float)));
+    hipStream_t s = (hipStream_t)stream;
+    // W[N][K] natural == "matrix with N rows of length K": its B-operand packing equals the A-operand packing
+    int rc = launch_repack_rows(d_w, wp, K, N, K, 0, s);
+    Linear l; l.w = d_w; l.wp = wp; l.b = d_bias; l.in = K; l.out = N;
+    if (!rc) rc = launch_gemm_skinny(lin_params(l, dp_static(d_x, K), M, dp_static(d_y, N)), act ? EPI_ELU : EPI_LINEAR, s);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(wp);
+    if (!rc && e != hipSuccess) { set_error("bvc_test_linear: %s", hipGetErrorString(e)); rc = BVC_EHIP; }
+    return rc;
 }
 
 int bvc_test_linear_batched(const float *d_x, const float *d_w, const float *d_bias, int32_t M, int32_t N, int32_t K,

@@ -29,36 +29,48 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 __device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : expf(v) - 1.0f; }
 __device__ __forceinline__ float sigmoid1(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-struct Resolved { float *p; long long ld; bool ok; };
+struct Resolved { float *p; long long ld; bool ok; int packed; };
 
-__device__ __forceinline__ Resolved resolve(const DynPtr &d, const CallDesc *c, int t, long long T) {
-    if (d.kind == 0) return {d.base, d.ld, d.base != nullptr};
-    if (d.kind == 2) return {d.base + (((t + d.toff) & 1) ? d.poff : 0), d.ld, true};
+// Effective address of a DynPtr for frame t.  Packed frame tensors hold one fragment-packed
+// [mt16][dim] matrix per frame (mt16 = rows rounded up to 16).
+__device__ __forceinline__ Resolved resolve(const DynPtr &d, const CallDesc *c, int t, long long T, int mt16) {
+    if (d.kind == 0) return {d.base, d.ld, d.base != nullptr, d.packed};
+    if (d.kind == 2) return {d.base + (((t + d.toff) & 1) ? d.poff : 0), d.ld, true, d.packed};
     float *b = c->p[d.sel];
     const long long tt = (long long)t + d.toff;
     const bool ok = (b != nullptr) && tt >= 0 && tt < T;
-    return {ok ? b + tt * d.dim : nullptr, T * d.dim, ok};
+    if (d.packed) return {ok ? b + tt * (long long)mt16 * d.dim : nullptr, (long long)d.dim, ok, 1};
+    return {ok ? b + tt * d.dim : nullptr, T * d.dim, ok, 0};
 }
 
-// Accumulate blocks [lo, hi) (16 k each) of one segment into acc[NG].  Rows beyond M read a clamped
-// (valid) row: output row i of an MFMA tile depends only on operand row i, and those rows are never stored.
+// offset (in floats) of element (m, n) of a fragment-packed [.][ld] matrix
+__device__ __forceinline__ long long packed_off(int m, int n, long long ld) {
+    return ((((long long)(m >> 4) * (ld >> 4) + (n >> 4)) * 64 + ((n & 15) >> 2) * 16 + (m & 15)) << 2) + (n & 3);
+}
+
+__device__ __forceinline__ void store_out(const Resolved &y, int m, int n, float v) {
+    if (y.packed) y.p[packed_off(m, n, y.ld)] = v;
+    else y.p[(long long)m * y.ld + n] = v;
+}
+
+// Accumulate k-blocks [lo, hi) of one segment into acc[NG].  wl: this lane's pointer into the packed
+// weights of (n-tile, gate 0, k-block 0); xl: this lane's pointer to k-block 0 of its operand row
+// (xstep floats per k-block).  Weight loads are issued first: they do not depend on the call
+// descriptor, so they are in flight while the descriptor-dependent activation address resolves.
 template <int NG, int U>
-__device__ __forceinline__ void run_segment(const float *w, long long ldw, int lo, int hi, const float *xrow_base,
-                                            int wrow0, long long gate_rows, int g, f32x4 (&acc)[NG]) {
-    const float *xb = xrow_base + (long long)g * 4;
-    const float *wb = w + (long long)wrow0 * ldw + (long long)g * 4;
+__device__ __forceinline__ void run_segment(const float *wl, long long gate_stride, const float *xl, int xstep,
+                                            int lo, int hi, f32x4 (&acc)[NG]) {
     int kb = lo;
     for (; kb + U <= hi; kb += U) {
         f32x4 xv[U];
         f32x4 wv[U][NG];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            xv[u] = *reinterpret_cast<const f32x4 *>(xb + (long long)(kb + u) * 16);
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int q = 0; q < NG; ++q)
-                wv[u][q] = *reinterpret_cast<const f32x4 *>(wb + (long long)q * gate_rows * ldw +
-                                                            (long long)(kb + u) * 16);
-        }
+                wv[u][q] = *reinterpret_cast<const f32x4 *>(wl + (long long)q * gate_stride + (long long)(kb + u) * 256);
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const f32x4 *>(xl + (long long)(kb + u) * xstep);
         __builtin_amdgcn_sched_barrier(0);      // keep all U blocks' loads in flight ahead of the MFMAs
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -69,13 +81,15 @@ __device__ __forceinline__ void run_segment(const float *w, long long ldw, int l
         }
     }
     for (; kb < hi; ++kb) {
-        f32x4 xv = *reinterpret_cast<const f32x4 *>(xb + (long long)kb * 16);
+        f32x4 wv[NG];
 #pragma unroll
-        for (int q = 0; q < NG; ++q) {
-            f32x4 wv = *reinterpret_cast<const f32x4 *>(wb + (long long)q * gate_rows * ldw + (long long)kb * 16);
+        for (int q = 0; q < NG; ++q)
+            wv[q] = *reinterpret_cast<const f32x4 *>(wl + (long long)q * gate_stride + (long long)kb * 256);
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xl + (long long)kb * xstep);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[q] = mfma16(xv[e], wv[e], acc[q]);
-        }
+        for (int q = 0; q < NG; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[q] = mfma16(xv[e], wv[q][e], acc[q]);
     }
 }
 
@@ -92,6 +106,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
 
     const int n_tiles = p.N >> 4;
     const int m_tiles = (p.M + 15) >> 4;
+    const int mt16 = m_tiles << 4;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
     const int ntile = (slot / m_tiles) * 8 + xcd;
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     for (int s = 0; s < p.nseg; ++s) nb += p.seg[s].K >> 4;
     const int my_lo = (int)(((long long)nb * wave) / NW);
     const int my_hi = (int)(((long long)nb * (wave + 1)) / NW);
-    const int xrow = (m0 + r) < p.M ? (m0 + r) : (p.M - 1);
+    const int xrow = (m0 + r) < p.M ? (m0 + r) : (p.M - 1);      // natural layout: clamp (row never stored)
 
     int base = 0;
     for (int s = 0; s < p.nseg; ++s) {
@@ -120,12 +135,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
         lo = lo < 0 ? 0 : lo;
         hi = hi > sb ? sb : hi;
         if (lo < hi) {
-            const Resolved x = resolve(p.seg[s].x, dsc, t, T);
-            const float *xrow_base = x.p + (long long)xrow * x.ld;
-            if (NGRP == 1 || p.seg[s].grp == 0)
-                run_segment<NG, U>(p.seg[s].w, p.seg[s].ldw, lo, hi, xrow_base, n0 + r, p.gate_rows, g, acc0);
-            else
-                run_segment<NG, U>(p.seg[s].w, p.seg[s].ldw, lo, hi, xrow_base, n0 + r, p.gate_rows, g, acc1);
+            const long long gate_stride = (long long)(p.gate_rows >> 4) * p.seg[s].wnb * 256;
+            const float *wl = p.seg[s].w + (long long)ntile * p.seg[s].wnb * 256 + lane * 4;
+            const Resolved x = resolve(p.seg[s].x, dsc, t, T, mt16);
+            const float *xl;
+            int xstep;
+            if (x.packed) { xl = x.p + (long long)mtile * (x.ld >> 4) * 256 + lane * 4; xstep = 256; }
+            else          { xl = x.p + (long long)xrow * x.ld + g * 4;                  xstep = 16; }
+            if (NGRP == 1 || p.seg[s].grp == 0) run_segment<NG, U>(wl, gate_stride, xl, xstep, lo, hi, acc0);
+            else                                run_segment<NG, U>(wl, gate_stride, xl, xstep, lo, hi, acc1);
         }
         base += sb;
     }
@@ -153,28 +171,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     const int i = tid >> 4, j = tid & 15;
     const int m = m0 + i, n = n0 + j;
     if (m < p.M) {
-        const Resolved y = resolve(p.y, dsc, t, T);
+        const Resolved y = resolve(p.y, dsc, t, T, mt16);
         if (epi == EPI_LINEAR || epi == EPI_ELU) {
             float o = v[0] + p.bias0[n];
             if (epi == EPI_ELU) o = elu1(o);
-            y.p[(long long)m * y.ld + n] = o;
+            store_out(y, m, n, o);
         } else if (epi == EPI_CODE) {
             const float logit = v[0] + p.bias0[n];
             const float pr = sigmoid1(logit);
             float z = rintf(pr);                                     // round half to even (torch.round)
             if (p.var_bit) {
-                const Resolved bt = resolve(p.aux, dsc, t, T);
+                const Resolved bt = resolve(p.aux, dsc, t, T, mt16);
                 const float bits = bt.p[(long long)m * bt.ld];
                 z = (bits > (float)n) ? z : 0.5f;                    // z*m + 0.5*(1-m)
             }
-            y.p[(long long)m * y.ld + n] = z;
-            const Resolved y3 = resolve(p.y3, dsc, t, T);
-            if (y3.ok) y3.p[(long long)m * y3.ld + n] = pr;
+            store_out(y, m, n, z);
+            const Resolved y3 = resolve(p.y3, dsc, t, T, mt16);
+            if (y3.ok) store_out(y3, m, n, pr);
         } else if (epi == EPI_MEL) {
             const float d = v[0] + p.bias0[n];
-            if (y.ok) y.p[(long long)m * y.ld + n] = d;
-            const Resolved y2 = resolve(p.y2, dsc, t, T);
-            y2.p[(long long)m * y2.ld + n] = (d - p.mean[n]) / p.stdv[n];
+            if (y.ok) store_out(y, m, n, d);
+            const Resolved y2 = resolve(p.y2, dsc, t, T, mt16);
+            store_out(y2, m, n, (d - p.mean[n]) / p.stdv[n]);
         } else if (NGRP > 1 && NG == 3) {                            // EPI_GRU
             const long long H = p.gate_rows;
             const float gi_r = v[0] + p.bias0[n], gi_z = v[1] + p.bias0[H + n], gi_n = v[2] + p.bias0[2 * H + n];
@@ -184,12 +202,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             const float rg = sigmoid1(gh_r + gi_r);
             const float zg = sigmoid1(gh_z + gi_z);
             const float ng = tanhf(gi_n + rg * gh_n);
-            const Resolved hprev = resolve(p.aux, dsc, t, T);
-            const float hp = hprev.p[(long long)m * hprev.ld + n];
+            const Resolved hprev = resolve(p.aux, dsc, t, T, mt16);
+            const float hp = hprev.packed ? hprev.p[packed_off(m, n, hprev.ld)] : hprev.p[(long long)m * hprev.ld + n];
             const float hn = (hp - ng) * zg + ng;
-            y.p[(long long)m * y.ld + n] = hn;
-            const Resolved y2 = resolve(p.y2, dsc, t, T);
-            if (y2.ok) y2.p[(long long)m * y2.ld + n] = hn;
+            store_out(y, m, n, hn);
+            const Resolved y2 = resolve(p.y2, dsc, t, T, mt16);
+            if (y2.ok) store_out(y2, m, n, hn);
         }
     }
     if (probe && tid == 0)
@@ -213,10 +231,11 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s) {
     if (p.N % 16) { set_error("gemm_skinny: N=%d not a multiple of 16", p.N); return BVC_EINVAL; }
     int nb = 0;
     for (int i = 0; i < p.nseg; ++i) {
-        if (p.seg[i].K % 16 || p.seg[i].ldw % 4 || (p.seg[i].x.kind != 1 && p.seg[i].x.ld % 4) ||
-            (p.seg[i].x.kind == 1 && p.seg[i].x.dim % 4)) {
-            set_error("gemm_skinny: segment %d K=%d ldw=%lld: K must be a multiple of 16, strides of 4", i,
-                      p.seg[i].K, p.seg[i].ldw);
+        const DynPtr &x = p.seg[i].x;
+        const long long xl = x.kind == 1 ? x.dim : x.ld;
+        if (p.seg[i].K % 16 || xl % (x.packed ? 16 : 4) || p.seg[i].wnb <= 0) {
+            set_error("gemm_skinny: segment %d K=%d row length %lld: K must be a multiple of 16, rows of 4 (16 packed)",
+                      i, p.seg[i].K, xl);
             return BVC_EINVAL;
         }
         nb += p.seg[i].K / 16;
@@ -257,7 +276,8 @@ template <int ACT>
 __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restrict__ x, long long ldx,
                                                            const float *__restrict__ w, long long ldw,
                                                            const float *__restrict__ bias, int M, int N,
-                                                           int K, float *__restrict__ y, long long ldy) {
+                                                           int K, float *__restrict__ y, long long ldy,
+                                                           long long frames_T, int mt16) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -312,14 +332,19 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
                 if (row < M) {
                     float v = acc[i][j][e] + b;
                     if (ACT == 1) v = elu1(v);
-                    y[(long long)row * ldy + col] = v;
+                    if (frames_T > 0) {                          // row = b * T + t -> packed [B][N] matrix of frame t
+                        const long long bb = row / frames_T, tt = row - bb * frames_T;
+                        y[tt * (long long)mt16 * N + packed_off((int)bb, col, N)] = v;
+                    } else {
+                        y[(long long)row * ldy + col] = v;
+                    }
                 }
             }
     }
 }
 
 int launch_gemm_batched(const float *x, long long ldx, const float *w, long long ldw, const float *bias,
-                        int M, int N, int K, int act, float *y, long long ldy, hipStream_t s) {
+                        int M, int N, int K, int act, float *y, long long ldy, hipStream_t s, long long frames_T) {
     if (M <= 0) return BVC_OK;
     if (K % 16 || ldx % 4 || ldw % 4) {
         set_error("gemm_batched: K=%d ldx=%lld ldw=%lld must be multiples of 16/4/4", K, ldx, ldw);
@@ -327,10 +352,15 @@ int launch_gemm_batched(const float *x, long long ldx, const float *w, long long
     }
     dim3 grid((N + 127) / 128, (M + 127) / 128);
     ProbeScope probe(PK_BATCHED, s);
+    int mt16 = 0;
+    if (frames_T > 0) {
+        if (M % frames_T || N % 16) { set_error("gemm_batched: frame-packed output needs M %% T == 0, N %% 16 == 0"); return BVC_EINVAL; }
+        mt16 = (int)(((M / frames_T) + 15) / 16) * 16;
+    }
     if (act == 1)
-        hipLaunchKernelGGL(gemm_batched_kernel<1>, grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy);
+        hipLaunchKernelGGL(gemm_batched_kernel<1>, grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16);
     else
-        hipLaunchKernelGGL(gemm_batched_kernel<0>, grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy);
+        hipLaunchKernelGGL(gemm_batched_kernel<0>, grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }
@@ -352,6 +382,26 @@ int launch_normalize_rows(const float *y, const float *mean, const float *stdv, 
     if (total <= 0) return BVC_OK;
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(normalize_rows_kernel, dim3(grid), dim3(256), 0, s, y, mean, stdv, total, n, out);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
+__global__ void repack_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, long long ld, int rows,
+                                   int n, int dir) {
+    const long long total = (long long)rows * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n), c = (int)(i % n);
+        if (dir == 0) dst[packed_off(m, c, n)] = src[(long long)m * ld + c];
+        else          dst[(long long)m * ld + c] = src[packed_off(m, c, n)];
+    }
+}
+
+int launch_repack_rows(const float *src, float *dst, long long ld_natural, int rows, int n, int dir, hipStream_t s) {
+    const long long total = (long long)rows * n;
+    if (total <= 0) return BVC_OK;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(repack_rows_kernel, dim3(grid), dim3(256), 0, s, src, dst, ld_natural, rows, n, dir);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }
