@@ -38,7 +38,6 @@ struct ProbeScope {
 enum DescSlot { DS_PX = 0, DS_CODES = 1, DS_BITS = 2, DS_PROB = 3, DS_ALLH = 4, DS_MEL = 5, DS_PZ = 6, DS_NSLOT = 8 };
 struct CallDesc {
     float *p[DS_NSLOT];              // base pointers of the (B, T, dim) tensors of this call (may be null)
-    unsigned long long *probe;       // in-kernel timing slots [2 * launches] or null (bench only)
     long long T;                     // frames per utterance
     int t;                           // current frame
     int nodes_per_step;              // kernels per step (probe slot = t * nodes_per_step + node)
@@ -93,7 +92,8 @@ struct GemmParams {
     DynPtr  aux;               // CODE: bits per frame (one per row); GRU: previous h
     const float *mean; const float *stdv; // MEL epilogue
     int     var_bit;
-    const CallDesc *desc;      // null for stand-alone launches (t = 0)
+    const CallDesc *desc;      // null for stand-alone launches (all pointers static)
+    unsigned long long *probe; // in-kernel timing slots, set only in the probe variant of a step graph
     int     node;              // index of this kernel inside its step (probe slot)
 };
 

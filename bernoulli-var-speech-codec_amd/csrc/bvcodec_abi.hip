@@ -75,7 +75,7 @@ struct bvc_model {
     const float *post_a = nullptr, *post_ib = nullptr, *post_w = nullptr, *post_b = nullptr;
     int post_c = 0, post_ks = 7;
     // captured recurrent steps (hipGraph), keyed by (kind, batch, workspace)
-    struct StepGraph { int kind; int B; void *ws; hipGraphExec_t exec1, execN; };
+    struct StepGraph { int kind; int B; void *ws; void *probe; hipGraphExec_t exec1, execN; };
     mutable std::vector<StepGraph> graphs;
     mutable hipStream_t cap_stream = nullptr;
     bool use_graph = true;
@@ -517,7 +517,10 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
         p.aux = h_cur;
         plan.push_back({p, EPI_GRU});
     }
-    for (size_t i = 0; i < plan.size(); ++i) { plan[i].p.desc = w.desc; plan[i].p.node = (int)i; }
+    for (size_t i = 0; i < plan.size(); ++i) {
+        plan[i].p.desc = w.desc; plan[i].p.node = (int)i;
+        plan[i].p.probe = g_kprobe.enabled ? g_kprobe.dev : nullptr;
+    }
     return plan;
 }
 
@@ -536,10 +539,11 @@ constexpr int GRAPH_STEPS = 8;
 // Returns the cached graph pair for (kind, B, workspace), capturing it on first use.
 int get_step_graph(const bvc_model *m, const Workspace &w, void *ws_base, int B, int kind,
                    const std::vector<StepNode> &plan, const bvc_model::StepGraph **out) {
+    void *probe = g_kprobe.enabled ? (void *)g_kprobe.dev : nullptr;
     for (const auto &g : m->graphs)
-        if (g.kind == kind && g.B == B && g.ws == ws_base) { *out = &g; return BVC_OK; }
+        if (g.kind == kind && g.B == B && g.ws == ws_base && g.probe == probe) { *out = &g; return BVC_OK; }
     if (!m->cap_stream) BVC_HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
-    bvc_model::StepGraph sg{kind, B, ws_base, nullptr, nullptr};
+    bvc_model::StepGraph sg{kind, B, ws_base, probe, nullptr, nullptr};
     for (int which = 0; which < 2; ++which) {
         hipGraph_t graph = nullptr;
         g_capturing = true;
@@ -580,14 +584,13 @@ int begin_call(const bvc_model *m, const Workspace &w, const CallDesc &v, int st
     CallDesc d = v;
     d.t = 0;
     d.nodes_per_step = steps_nodes;
-    d.probe = nullptr;
     if (g_kprobe.enabled) {
         const size_t need = (size_t)2 * d.T * steps_nodes;
-        if (need <= g_kprobe.capacity) {
+        if (need > g_kprobe.capacity) { set_error("kprobe buffer too small for T=%lld", (long long)d.T); return BVC_EINVAL; }
+        {
             // first half: start stamps (atomicMin, so all ones); second half: end stamps (atomicMax, so zero)
             BVC_HIP_TRY(hipMemsetAsync(g_kprobe.dev, 0xFF, need / 2 * sizeof(unsigned long long), s));
             BVC_HIP_TRY(hipMemsetAsync(g_kprobe.dev + need / 2, 0, need / 2 * sizeof(unsigned long long), s));
-            d.probe = g_kprobe.dev;
             g_kprobe.T = d.T; g_kprobe.nodes = steps_nodes;
         }
     }

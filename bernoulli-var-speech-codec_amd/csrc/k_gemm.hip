@@ -33,9 +33,13 @@ struct Resolved { float *p; long long ld; bool ok; int packed; };
 
 // Effective address of a DynPtr for frame t.  Packed frame tensors hold one fragment-packed
 // [mt16][dim] matrix per frame (mt16 = rows rounded up to 16).
-__device__ __forceinline__ Resolved resolve(const DynPtr &d, const CallDesc *c, int t, long long T, int mt16) {
+// The frame counter is read from the descriptor only by pointers that need it (kind 1/2): layers whose
+// operands are all workspace-static never wait for that line.
+__device__ __forceinline__ Resolved resolve(const DynPtr &d, const CallDesc *c, int mt16) {
     if (d.kind == 0) return {d.base, d.ld, d.base != nullptr, d.packed};
+    const int t = c->t;
     if (d.kind == 2) return {d.base + (((t + d.toff) & 1) ? d.poff : 0), d.ld, true, d.packed};
+    const long long T = c->T;
     float *b = c->p[d.sel];
     const long long tt = (long long)t + d.toff;
     const bool ok = (b != nullptr) && tt >= 0 && tt < T;
@@ -54,12 +58,23 @@ __device__ __forceinline__ void store_out(const Resolved &y, int m, int n, float
 }
 
 // Accumulate k-blocks [lo, hi) of one segment into acc[NG].  wl: this lane's pointer into the packed
-// weights of (n-tile, gate 0, k-block 0); xl: this lane's pointer to k-block 0 of its operand row
-// (xstep floats per k-block).  Weight loads are issued first: they do not depend on the call
-// descriptor, so they are in flight while the descriptor-dependent activation address resolves.
+// weights of (n-tile, gate 0, k-block 0).  The weight loads of the first chunk are issued BEFORE the
+// activation pointer is resolved: weight addresses come from kernel arguments only, while a frame- or
+// parity-indexed activation pointer needs the frame counter from the call descriptor (a dependent
+// load of a line another kernel has just written), whose latency is thus hidden behind the weights.
 template <int NG, int U>
-__device__ __forceinline__ void run_segment(const float *wl, long long gate_stride, const float *xl, int xstep,
+__device__ __forceinline__ void run_segment(const float *wl, long long gate_stride, const DynPtr &xd,
+                                            const CallDesc *dsc, int mt16, int mtile, int xrow, int lane, int g,
                                             int lo, int hi, f32x4 (&acc)[NG]) {
+    const float *xl = nullptr;
+    int xstep = 0;
+    bool have_x = false;
+    auto resolve_x = [&]() {
+        const Resolved x = resolve(xd, dsc, mt16);
+        if (x.packed) { xl = x.p + (long long)mtile * (x.ld >> 4) * 256 + lane * 4; xstep = 256; }
+        else          { xl = x.p + (long long)xrow * x.ld + g * 4;                  xstep = 16; }
+        have_x = true;
+    };
     int kb = lo;
     for (; kb + U <= hi; kb += U) {
         f32x4 xv[U];
@@ -69,6 +84,7 @@ __device__ __forceinline__ void run_segment(const float *wl, long long gate_stri
 #pragma unroll
             for (int q = 0; q < NG; ++q)
                 wv[u][q] = *reinterpret_cast<const f32x4 *>(wl + (long long)q * gate_stride + (long long)(kb + u) * 256);
+        if (!have_x) resolve_x();
 #pragma unroll
         for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const f32x4 *>(xl + (long long)(kb + u) * xstep);
         __builtin_amdgcn_sched_barrier(0);      // keep all U blocks' loads in flight ahead of the MFMAs
@@ -85,6 +101,7 @@ __device__ __forceinline__ void run_segment(const float *wl, long long gate_stri
 #pragma unroll
         for (int q = 0; q < NG; ++q)
             wv[q] = *reinterpret_cast<const f32x4 *>(wl + (long long)q * gate_stride + (long long)kb * 256);
+        if (!have_x) resolve_x();
         const f32x4 xv = *reinterpret_cast<const f32x4 *>(xl + (long long)kb * xstep);
 #pragma unroll
         for (int q = 0; q < NG; ++q)
@@ -98,11 +115,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][NGRP*NG][256]
     const int tid = threadIdx.x, lane = tid & 63;
     const CallDesc *dsc = p.desc;
-    const int t = dsc ? dsc->t : 0;
-    const long long T = dsc ? dsc->T : 1;
-    unsigned long long *probe = dsc ? dsc->probe : nullptr;
-    if (probe && tid == 0)       // slots: [0, T*nodes) first-wave start times, [T*nodes, 2*T*nodes) last end times
-        atomicMin(&probe[(long long)t * dsc->nodes_per_step + p.node], (unsigned long long)wall_clock64());
+    unsigned long long t_start = 0;
+    if (p.probe) t_start = wall_clock64();                           // probe builds of the graph only
 
     const int n_tiles = p.N >> 4;
     const int m_tiles = (p.M + 15) >> 4;
@@ -115,6 +129,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     const int m0 = mtile << 4, n0 = ntile << 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
+
+    // epilogue constants are fetched up front so their latency overlaps the operand stream
+    constexpr int NACC = NG * NGRP;
+    float bias[NACC];
+    if (tid < 256) {
+        const int n = n0 + (tid & 15);
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            bias[q] = p.bias0[(long long)q * p.gate_rows + n];
+            if (NGRP > 1) bias[NG + q] = p.bias1[(long long)q * p.gate_rows + n];
+        }
+    }
 
     f32x4 acc0[NG], acc1[NGRP > 1 ? NG : 1];
 #pragma unroll
@@ -137,19 +163,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
         if (lo < hi) {
             const long long gate_stride = (long long)(p.gate_rows >> 4) * p.seg[s].wnb * 256;
             const float *wl = p.seg[s].w + (long long)ntile * p.seg[s].wnb * 256 + lane * 4;
-            const Resolved x = resolve(p.seg[s].x, dsc, t, T, mt16);
-            const float *xl;
-            int xstep;
-            if (x.packed) { xl = x.p + (long long)mtile * (x.ld >> 4) * 256 + lane * 4; xstep = 256; }
-            else          { xl = x.p + (long long)xrow * x.ld + g * 4;                  xstep = 16; }
-            if (NGRP == 1 || p.seg[s].grp == 0) run_segment<NG, U>(wl, gate_stride, xl, xstep, lo, hi, acc0);
-            else                                run_segment<NG, U>(wl, gate_stride, xl, xstep, lo, hi, acc1);
+            if (NGRP == 1 || p.seg[s].grp == 0)
+                run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, mtile, xrow, lane, g, lo, hi, acc0);
+            else
+                run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, mtile, xrow, lane, g, lo, hi, acc1);
         }
         base += sb;
     }
 
     // ---- cross-wave reduction through LDS, fixed order (deterministic)
-    constexpr int NACC = NG * NGRP;
 #pragma unroll
     for (int q = 0; q < NG; ++q)
 #pragma unroll
@@ -166,52 +188,51 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
         float sum = red[a * 256 + tid];
 #pragma unroll
         for (int w = 1; w < NW; ++w) sum += red[(w * NACC + a) * 256 + tid];
-        v[a] = sum;
+        v[a] = sum + bias[a];
     }
     const int i = tid >> 4, j = tid & 15;
     const int m = m0 + i, n = n0 + j;
     if (m < p.M) {
-        const Resolved y = resolve(p.y, dsc, t, T, mt16);
+        const Resolved y = resolve(p.y, dsc, mt16);
         if (epi == EPI_LINEAR || epi == EPI_ELU) {
-            float o = v[0] + p.bias0[n];
+            float o = v[0];
             if (epi == EPI_ELU) o = elu1(o);
             store_out(y, m, n, o);
         } else if (epi == EPI_CODE) {
-            const float logit = v[0] + p.bias0[n];
-            const float pr = sigmoid1(logit);
+            const float pr = sigmoid1(v[0]);
             float z = rintf(pr);                                     // round half to even (torch.round)
             if (p.var_bit) {
-                const Resolved bt = resolve(p.aux, dsc, t, T, mt16);
+                const Resolved bt = resolve(p.aux, dsc, mt16);
                 const float bits = bt.p[(long long)m * bt.ld];
                 z = (bits > (float)n) ? z : 0.5f;                    // z*m + 0.5*(1-m)
             }
             store_out(y, m, n, z);
-            const Resolved y3 = resolve(p.y3, dsc, t, T, mt16);
+            const Resolved y3 = resolve(p.y3, dsc, mt16);
             if (y3.ok) store_out(y3, m, n, pr);
         } else if (epi == EPI_MEL) {
-            const float d = v[0] + p.bias0[n];
+            const float d = v[0];
             if (y.ok) store_out(y, m, n, d);
-            const Resolved y2 = resolve(p.y2, dsc, t, T, mt16);
+            const Resolved y2 = resolve(p.y2, dsc, mt16);
             store_out(y2, m, n, (d - p.mean[n]) / p.stdv[n]);
         } else if (NGRP > 1 && NG == 3) {                            // EPI_GRU
-            const long long H = p.gate_rows;
-            const float gi_r = v[0] + p.bias0[n], gi_z = v[1] + p.bias0[H + n], gi_n = v[2] + p.bias0[2 * H + n];
-            const float gh_r = v[NACC > 3 ? 3 : 0] + p.bias1[n];
-            const float gh_z = v[NACC > 4 ? 4 : 0] + p.bias1[H + n];
-            const float gh_n = v[NACC > 5 ? 5 : 0] + p.bias1[2 * H + n];
+            const float gi_r = v[0], gi_z = v[1], gi_n = v[2];
+            const float gh_r = v[NACC > 3 ? 3 : 0], gh_z = v[NACC > 4 ? 4 : 0], gh_n = v[NACC > 5 ? 5 : 0];
             const float rg = sigmoid1(gh_r + gi_r);
             const float zg = sigmoid1(gh_z + gi_z);
             const float ng = tanhf(gi_n + rg * gh_n);
-            const Resolved hprev = resolve(p.aux, dsc, t, T, mt16);
+            const Resolved hprev = resolve(p.aux, dsc, mt16);
             const float hp = hprev.packed ? hprev.p[packed_off(m, n, hprev.ld)] : hprev.p[(long long)m * hprev.ld + n];
             const float hn = (hp - ng) * zg + ng;
             store_out(y, m, n, hn);
-            const Resolved y2 = resolve(p.y2, dsc, t, T, mt16);
+            const Resolved y2 = resolve(p.y2, dsc, mt16);
             if (y2.ok) store_out(y2, m, n, hn);
         }
     }
-    if (probe && tid == 0)
-        atomicMax(&probe[(T + t) * dsc->nodes_per_step + p.node], (unsigned long long)wall_clock64());
+    if (p.probe && tid == 0) {   // slots: [0, T*nodes) first-workgroup start, [T*nodes, 2*T*nodes) last end
+        const long long slot_i = (long long)dsc->t * dsc->nodes_per_step + p.node;
+        atomicMin(&p.probe[slot_i], t_start);
+        atomicMax(&p.probe[dsc->T * dsc->nodes_per_step + slot_i], (unsigned long long)wall_clock64());
+    }
 }
 
 template <int NG, int NGRP, int NW, int U>
