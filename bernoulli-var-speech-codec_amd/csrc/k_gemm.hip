@@ -33,14 +33,29 @@ struct Resolved { float *p; long long ld; bool ok; int packed; };
 
 // Effective address of a DynPtr for frame t.  Packed frame tensors hold one fragment-packed
 // [mt16][dim] matrix per frame (mt16 = rows rounded up to 16).
+// Scalar loads of call-descriptor fields.  hipcc emits VECTOR loads for these (the descriptor is not
+// provably invariant), and then waits vmcnt(0) for them - which also waits for every weight load issued
+// just before.  s_load + lgkmcnt keeps the descriptor off the vector-memory counter.  (The scalar cache
+// is invalidated by the acquire at every kernel dispatch, like for kernel arguments.)
+__device__ __forceinline__ int sload_i32(const void *p) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ long long sload_i64(const void *p) {
+    long long v;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
 // The frame counter is read from the descriptor only by pointers that need it (kind 1/2): layers whose
 // operands are all workspace-static never wait for that line.
 __device__ __forceinline__ Resolved resolve(const DynPtr &d, const CallDesc *c, int mt16) {
     if (d.kind == 0) return {d.base, d.ld, d.base != nullptr, d.packed};
-    const int t = c->t;
+    const int t = sload_i32(&c->t);
     if (d.kind == 2) return {d.base + (((t + d.toff) & 1) ? d.poff : 0), d.ld, true, d.packed};
-    const long long T = c->T;
-    float *b = c->p[d.sel];
+    const long long T = sload_i64(&c->T);
+    float *b = reinterpret_cast<float *>(sload_i64(&c->p[d.sel]));
     const long long tt = (long long)t + d.toff;
     const bool ok = (b != nullptr) && tt >= 0 && tt < T;
     if (d.packed) return {ok ? b + tt * (long long)mt16 * d.dim : nullptr, (long long)d.dim, ok, 1};
@@ -149,13 +164,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     for (int q = 0; q < (NGRP > 1 ? NG : 1); ++q) acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int nb = 0;
-    for (int s = 0; s < p.nseg; ++s) nb += p.seg[s].K >> 4;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) nb += (s < p.nseg) ? (p.seg[s].K >> 4) : 0;
     const int my_lo = (int)(((long long)nb * wave) / NW);
     const int my_hi = (int)(((long long)nb * (wave + 1)) / NW);
     const int xrow = (m0 + r) < p.M ? (m0 + r) : (p.M - 1);      // natural layout: clamp (row never stored)
 
     int base = 0;
-    for (int s = 0; s < p.nseg; ++s) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s >= p.nseg) break;
         const int sb = p.seg[s].K >> 4;
         int lo = my_lo - base, hi = my_hi - base;
         lo = lo < 0 ? 0 : lo;
@@ -229,9 +247,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
         }
     }
     if (p.probe && tid == 0) {   // slots: [0, T*nodes) first-workgroup start, [T*nodes, 2*T*nodes) last end
-        const long long slot_i = (long long)dsc->t * dsc->nodes_per_step + p.node;
+        const int nps = sload_i32(&dsc->nodes_per_step);
+        const long long slot_i = (long long)sload_i32(&dsc->t) * nps + p.node;
         atomicMin(&p.probe[slot_i], t_start);
-        atomicMax(&p.probe[dsc->T * dsc->nodes_per_step + slot_i], (unsigned long long)wall_clock64());
+        atomicMax(&p.probe[sload_i64(&dsc->T) * nps + slot_i], (unsigned long long)wall_clock64());
     }
 }
 
