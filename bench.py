@@ -113,7 +113,8 @@ def main():
     L = int(FS * a.seconds)
     B = a.batch
     x = synth.synthetic_speech(B, L, seed=rank, kind="noise").to(device)      # resident before timing
-    gathered = torch.empty(world * B, L, device=device) if (world > 1 and not a.no_gather) else None
+    use_pg = torch.distributed.is_available() and torch.distributed.is_initialized()
+    gathered = torch.empty(world * B, L, device=device) if (use_pg and not a.no_gather) else None
 
     def step():
         codes = model.encode(x, BITRATE)
@@ -138,16 +139,16 @@ def main():
         return last
 
     run(max(a.warmup, len(streams)) if a.warmup else 0)
-    if world > 1:
+    if use_pg:
         torch.distributed.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     codes, wav = run(a.steps)
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_pg:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -221,7 +222,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(conf)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -95,11 +95,12 @@ struct GemmParams {
     const CallDesc *desc;      // null for stand-alone launches (all pointers static)
     unsigned long long *probe; // in-kernel timing slots, set only in the probe variant of a step graph
     int     node;              // index of this kernel inside its step (probe slot)
+    int     tstep;             // static frame offset inside an unrolled multi-step graph: t = desc->t + tstep
 };
 
 int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s);
 int skinny_kernels_init();
-int launch_step_advance(CallDesc *d, hipStream_t s);
+int launch_step_advance(CallDesc *d, int by, hipStream_t s);
 int launch_set_desc(CallDesc *d, const CallDesc &v, hipStream_t s);
 
 // batched GEMM over all frames: y = act(x @ w^T + bias), M large

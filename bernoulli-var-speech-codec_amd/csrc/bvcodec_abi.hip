@@ -524,14 +524,17 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
     return plan;
 }
 
+// Launch `nsteps` consecutive frames; the frame counter is advanced ONCE at the end: frame k of the
+// group runs with the static offset tstep = k baked into its kernel arguments.
 int launch_steps(const std::vector<StepNode> &plan, const Workspace &w, int nsteps, hipStream_t s) {
     int rc;
-    for (int k = 0; k < nsteps; ++k) {
-        for (const StepNode &n : plan)
-            if ((rc = launch_gemm_skinny(n.p, n.epi, s))) return rc;
-        if ((rc = launch_step_advance(w.desc, s))) return rc;
-    }
-    return BVC_OK;
+    for (int k = 0; k < nsteps; ++k)
+        for (const StepNode &n : plan) {
+            GemmParams p = n.p;
+            p.tstep = k;
+            if ((rc = launch_gemm_skinny(p, n.epi, s))) return rc;
+        }
+    return launch_step_advance(w.desc, nsteps, s);
 }
 
 constexpr int GRAPH_STEPS = 8;
@@ -571,7 +574,12 @@ int get_step_graph(const bvc_model *m, const Workspace &w, void *ws_base, int B,
 int run_recurrence(const bvc_model *m, const Workspace &w, void *ws_base, int B, int64_t T, int kind, hipStream_t s) {
     const std::vector<StepNode> plan = build_step(m, w, B, kind);
     int rc;
-    if (!m->use_graph) return launch_steps(plan, w, (int)T, s);
+    if (!m->use_graph) {
+        int rc2;
+        for (int64_t t = 0; t < T; ++t)
+            if ((rc2 = launch_steps(plan, w, 1, s))) return rc2;
+        return BVC_OK;
+    }
     const bvc_model::StepGraph *g = nullptr;
     if ((rc = get_step_graph(m, w, ws_base, B, kind, plan, &g))) return rc;
     int64_t t = 0;

@@ -50,9 +50,9 @@ __device__ __forceinline__ long long sload_i64(const void *p) {
 
 // The frame counter is read from the descriptor only by pointers that need it (kind 1/2): layers whose
 // operands are all workspace-static never wait for that line.
-__device__ __forceinline__ Resolved resolve(const DynPtr &d, const CallDesc *c, int mt16) {
+__device__ __forceinline__ Resolved resolve(const DynPtr &d, const CallDesc *c, int mt16, int tstep) {
     if (d.kind == 0) return {d.base, d.ld, d.base != nullptr, d.packed};
-    const int t = sload_i32(&c->t);
+    const int t = sload_i32(&c->t) + tstep;
     if (d.kind == 2) return {d.base + (((t + d.toff) & 1) ? d.poff : 0), d.ld, true, d.packed};
     const long long T = sload_i64(&c->T);
     float *b = reinterpret_cast<float *>(sload_i64(&c->p[d.sel]));
@@ -79,13 +79,13 @@ __device__ __forceinline__ void store_out(const Resolved &y, int m, int n, float
 // load of a line another kernel has just written), whose latency is thus hidden behind the weights.
 template <int NG, int U>
 __device__ __forceinline__ void run_segment(const float *wl, long long gate_stride, const DynPtr &xd,
-                                            const CallDesc *dsc, int mt16, int mtile, int xrow, int lane, int g,
-                                            int lo, int hi, f32x4 (&acc)[NG]) {
+                                            const CallDesc *dsc, int mt16, int tstep, int mtile, int xrow, int lane,
+                                            int g, int lo, int hi, f32x4 (&acc)[NG]) {
     const float *xl = nullptr;
     int xstep = 0;
     bool have_x = false;
     auto resolve_x = [&]() {
-        const Resolved x = resolve(xd, dsc, mt16);
+        const Resolved x = resolve(xd, dsc, mt16, tstep);
         if (x.packed) { xl = x.p + (long long)mtile * (x.ld >> 4) * 256 + lane * 4; xstep = 256; }
         else          { xl = x.p + (long long)xrow * x.ld + g * 4;                  xstep = 16; }
         have_x = true;
@@ -182,9 +182,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             const long long gate_stride = (long long)(p.gate_rows >> 4) * p.seg[s].wnb * 256;
             const float *wl = p.seg[s].w + (long long)ntile * p.seg[s].wnb * 256 + lane * 4;
             if (NGRP == 1 || p.seg[s].grp == 0)
-                run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, mtile, xrow, lane, g, lo, hi, acc0);
+                run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
             else
-                run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, mtile, xrow, lane, g, lo, hi, acc1);
+                run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc1);
         }
         base += sb;
     }
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     const int i = tid >> 4, j = tid & 15;
     const int m = m0 + i, n = n0 + j;
     if (m < p.M) {
-        const Resolved y = resolve(p.y, dsc, mt16);
+        const Resolved y = resolve(p.y, dsc, mt16, p.tstep);
         if (epi == EPI_LINEAR || epi == EPI_ELU) {
             float o = v[0];
             if (epi == EPI_ELU) o = elu1(o);
@@ -220,17 +220,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             const float pr = sigmoid1(v[0]);
             float z = rintf(pr);                                     // round half to even (torch.round)
             if (p.var_bit) {
-                const Resolved bt = resolve(p.aux, dsc, mt16);
+                const Resolved bt = resolve(p.aux, dsc, mt16, p.tstep);
                 const float bits = bt.p[(long long)m * bt.ld];
                 z = (bits > (float)n) ? z : 0.5f;                    // z*m + 0.5*(1-m)
             }
             store_out(y, m, n, z);
-            const Resolved y3 = resolve(p.y3, dsc, mt16);
+            const Resolved y3 = resolve(p.y3, dsc, mt16, p.tstep);
             if (y3.ok) store_out(y3, m, n, pr);
         } else if (epi == EPI_MEL) {
             const float d = v[0];
             if (y.ok) store_out(y, m, n, d);
-            const Resolved y2 = resolve(p.y2, dsc, mt16);
+            const Resolved y2 = resolve(p.y2, dsc, mt16, p.tstep);
             store_out(y2, m, n, (d - p.mean[n]) / p.stdv[n]);
         } else if (NGRP > 1 && NG == 3) {                            // EPI_GRU
             const float gi_r = v[0], gi_z = v[1], gi_n = v[2];
@@ -238,17 +238,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             const float rg = sigmoid1(gh_r + gi_r);
             const float zg = sigmoid1(gh_z + gi_z);
             const float ng = tanhf(gi_n + rg * gh_n);
-            const Resolved hprev = resolve(p.aux, dsc, mt16);
+            const Resolved hprev = resolve(p.aux, dsc, mt16, p.tstep);
             const float hp = hprev.packed ? hprev.p[packed_off(m, n, hprev.ld)] : hprev.p[(long long)m * hprev.ld + n];
             const float hn = (hp - ng) * zg + ng;
             store_out(y, m, n, hn);
-            const Resolved y2 = resolve(p.y2, dsc, mt16);
+            const Resolved y2 = resolve(p.y2, dsc, mt16, p.tstep);
             if (y2.ok) store_out(y2, m, n, hn);
         }
     }
     if (p.probe && tid == 0) {   // slots: [0, T*nodes) first-workgroup start, [T*nodes, 2*T*nodes) last end
         const int nps = sload_i32(&dsc->nodes_per_step);
-        const long long slot_i = (long long)sload_i32(&dsc->t) * nps + p.node;
+        const long long slot_i = (long long)(sload_i32(&dsc->t) + p.tstep) * nps + p.node;
         atomicMin(&p.probe[slot_i], t_start);
         atomicMax(&p.probe[sload_i64(&dsc->T) * nps + slot_i], (unsigned long long)wall_clock64());
     }
@@ -290,12 +290,12 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s) {
     return BVC_OK;
 }
 
-__global__ void step_advance_kernel(CallDesc *d) {
-    if (threadIdx.x == 0) d->t = d->t + 1;
+__global__ void step_advance_kernel(CallDesc *d, int by) {
+    if (threadIdx.x == 0) d->t = d->t + by;
 }
 
-int launch_step_advance(CallDesc *d, hipStream_t s) {
-    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, d);
+int launch_step_advance(CallDesc *d, int by, hipStream_t s) {
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, d, by);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }

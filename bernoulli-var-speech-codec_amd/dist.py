@@ -22,7 +22,8 @@ def init_from_env():
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("BVC_FORCE_PG", "0") == "1"      # lets a 1-GPU box exercise the RCCL code path
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if use_cuda:
