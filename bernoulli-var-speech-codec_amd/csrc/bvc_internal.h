@@ -150,6 +150,9 @@ enum ConvEpi { CE_STORE = 0, CE_RES = 1, CE_RES_ACC = 2, CE_RES_ACC_DIV = 3 };
 int conv_kernels_init();
 int launch_conv_mfma(const ConvLayer &c, const float *in, long long Lin, float *out, long long Lout,
                      int B, int epi, const float *res, const float *acc, float divisor, hipStream_t s);
+// one fused AMPBlock1 iteration: out = x + conv2(S2(conv1_dil(S1(x)))) (+acc, /divisor per epi); c2.dil == 1
+int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, long long L, float *out, int B, int epi,
+                    const float *acc, float divisor, hipStream_t s);
 // SnakeBeta -> causal conv C->1 (k taps) -> tanh -> / div -> first n_out samples
 int launch_conv_post(const float *in, long long Lin, int C, int ks, const float *w, const float *bias,
                      const float *act_a, const float *act_ib, float div, float *wav, long long n_out,

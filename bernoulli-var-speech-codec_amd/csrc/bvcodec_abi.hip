@@ -79,6 +79,7 @@ struct bvc_model {
     mutable std::vector<StepGraph> graphs;
     mutable hipStream_t cap_stream = nullptr;
     bool use_graph = true;
+    bool fused_amp = true;
 
     ~bvc_model() {
         for (auto &g : graphs) { (void)hipGraphExecDestroy(g.exec1); (void)hipGraphExecDestroy(g.execN); }
@@ -682,7 +683,7 @@ int run_vocoder(const bvc_model *m, const Workspace &w, const float *d_mel, int 
             const float *cur = w.X;
             for (int d = 0; d < 3; ++d) {
                 const AmpPair &ap = m->amp[i][j][d];
-                if ((rc = launch_conv_mfma(ap.c1, cur, L, w.U, L, B, CE_STORE, nullptr, nullptr, 1.0f, s))) return rc;
+                if (!m->fused_amp && (rc = launch_conv_mfma(ap.c1, cur, L, w.U, L, B, CE_STORE, nullptr, nullptr, 1.0f, s))) return rc;
                 float *dst;
                 int epi = CE_RES;
                 if (d < 2) dst = (d == 0) ? w.P : w.Q;
@@ -691,7 +692,9 @@ int run_vocoder(const bvc_model *m, const Workspace &w, const float *d_mel, int 
                     epi = (j == 0) ? CE_RES : (j + 1 < c.n_resk ? CE_RES_ACC : CE_RES_ACC_DIV);
                     if (c.n_resk == 1) epi = CE_RES;
                 }
-                if ((rc = launch_conv_mfma(ap.c2, w.U, L, dst, L, B, epi, cur, w.XS, (float)c.n_resk, s))) return rc;
+                if (m->fused_amp) {
+                    if ((rc = launch_amp_pair(ap.c1, ap.c2, cur, L, dst, B, epi, w.XS, (float)c.n_resk, s))) return rc;
+                } else if ((rc = launch_conv_mfma(ap.c2, w.U, L, dst, L, B, epi, cur, w.XS, (float)c.n_resk, s))) return rc;
                 cur = dst;
             }
         }
@@ -738,6 +741,8 @@ int bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t n
     {
         const char *ng = getenv("BVC_NO_GRAPH");
         m->use_graph = !(ng && ng[0] == '1');
+        const char *ua = getenv("BVC_UNFUSED_AMP");
+        m->fused_amp = !(ua && ua[0] == '1');
     }
     if ((rc = build_frontend(m.get(), tm))) return rc;
     if ((rc = build_bvrnn(m.get(), tm))) return rc;

@@ -36,9 +36,26 @@ struct ConvArgs {
     int epi, ks, dil, cout, ntiles, tiles_per_batch;
 };
 
+// sin(x)^2 with |error| < 1.7e-7 for |x| < 2000 (three-constant Cody-Waite reduction by pi/2 with
+// fma, cephes minimax polynomials on [-pi/4, pi/4]; the square removes the quadrant sign).  ocml's
+// sinf is equally accurate but carries a Payne-Hanek path and costs ~3x the instructions; the
+// generator evaluates 476 of these per output sample.
+__device__ __forceinline__ float sin_squared(float x) {
+    const float k = rintf(x * 0.636619772367581343f);
+    float r = fmaf(-k, 1.57079625129699707031e+00f, x);
+    r = fmaf(-k, 7.54978941586159635335e-08f, r);
+    r = fmaf(-k, 5.39030252995776476554e-15f, r);
+    const float r2 = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
+                          r2 * r2, fmaf(-0.5f, r2, 1.0f));
+    const float v = (((int)k) & 1) ? cp : sp;
+    return v * v;
+}
+
+// SnakeBeta (activations.py:107-120): x + 1/(exp(beta)+1e-9) * sin(x*exp(alpha))^2
 __device__ __forceinline__ float snakebeta(float x, float a, float ib) {
-    const float s = sinf(__fmul_rn(x, a));
-    return __fadd_rn(x, __fmul_rn(ib, __fmul_rn(s, s)));
+    return __fadd_rn(x, __fmul_rn(ib, sin_squared(__fmul_rn(x, a))));
 }
 
 // CIN: input channels; NTW: 16-column tiles per workgroup; MT: 16-row tiles per wave.
@@ -140,6 +157,175 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One AMPBlock1 iteration in one kernel (models.py:106-119):
+//     x' = x + conv2( S2( conv1_dil( S1(x) ) ) )            S = SnakeBeta, both convs causal
+// Phase 1 parks S1(x) for the output rows plus both halos in LDS; phase 2 runs conv1 on the MFMA for
+// TR rows starting (ks-1) rows before the tile, applies bias + S2 and parks the result in a second LDS
+// tile (rows before t=0 are zero: the reference pads AFTER the activation); phase 3 runs conv2 on that
+// tile and fuses bias, residual, the sum over the three parallel AMP blocks and the final /3.
+// The intermediate never touches HBM: 2 tensor passes per iteration instead of 5.
+struct AmpArgs {
+    const float *x; float *out; const float *acc;
+    long long L;
+    const float *w1, *b1, *a1, *ib1;
+    const float *w2, *b2, *a2, *ib2;
+    float divisor;
+    int epi, ks, dil, tiles_per_batch;
+};
+
+template <int C, int MT>
+__global__ __launch_bounds__(256) void amp_pair_kernel(AmpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int S = C + 2;
+    constexpr int NT = (C + 15) / 16;
+    constexpr int C4 = C / 4;
+    constexpr int TR = 4 * MT * 16;                       // rows computed by each conv phase
+    constexpr int CGU = (C4 % 8 == 0) ? 8 : (C4 % 4 == 0) ? 4 : 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int ks = a.ks, dil = a.dil;
+    const int TT = TR - (ks - 1);                          // valid output rows of this workgroup
+    const int b = blockIdx.x / a.tiles_per_batch;
+    const long long t0 = (long long)(blockIdx.x % a.tiles_per_batch) * TT;
+    const int halo1 = (ks - 1) * dil;
+    const int rows1 = TR + halo1;                          // S1(x) rows [t0-(ks-1)-halo1, t0-(ks-1)+TR)
+    float *t1 = lds;
+    float *t2 = lds + rows1 * S;                           // S2(u) rows [t0-(ks-1), t0-(ks-1)+TR) (+ ks-1 spare)
+    const float *xb = a.x + (long long)b * a.L * C;
+    const long long tbase = t0 - (ks - 1);                 // global row of local row 0 of phase 2 / t2
+
+    // ---- phase 1: activated input span
+    for (int idx = tid; idx < rows1 * C4; idx += 256) {
+        const int row = idx / C4, c4 = idx - row * C4;
+        const long long tg = tbase - halo1 + row;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (tg >= 0 && tg < a.L) {
+            v = *reinterpret_cast<const f32x4 *>(xb + tg * C + c4 * 4);
+            const f32x4 aa = *reinterpret_cast<const f32x4 *>(a.a1 + c4 * 4);
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(a.ib1 + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = snakebeta(v[e], aa[e], bb[e]);
+        }
+        float2 *dst = reinterpret_cast<float2 *>(t1 + row * S + c4 * 4);
+        dst[0] = make_float2(v[0], v[1]);
+        dst[1] = make_float2(v[2], v[3]);
+    }
+    for (int idx = tid; idx < (ks - 1) * S; idx += 256) t2[TR * S + idx] = 0.0f;    // spare rows read by discarded outputs
+    __syncthreads();
+
+    const int mbase = wave * MT * 16;
+    f32x4 acc[MT][NT];
+    auto mma = [&](const float *tile, int d, const float *wp) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float *wl = wp + lane;
+        for (int j = 0; j < ks; ++j) {
+            const float *arow = tile + (mbase + r + j * d) * S + g;
+            const float *wj = wl + (long long)j * C4 * NT * 64;
+#pragma unroll 1
+            for (int cg0 = 0; cg0 < C4; cg0 += CGU) {
+                float bw[CGU][NT];
+#pragma unroll
+                for (int u = 0; u < CGU; ++u)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) bw[u][n] = wj[((cg0 + u) * NT + n) * 64];
+#pragma unroll
+                for (int u = 0; u < CGU; ++u) {
+                    float av[MT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) av[i] = arow[i * 16 * S + (cg0 + u) * 4];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bw[u][n], acc[i][n], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- phase 2: u = conv1(S1(x)) ; t2 = S2(u + b1), zero before the start of the signal
+    mma(t1, dil, a.w1);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = n * 16 + r;
+        if (col < C) {
+            const float bias = a.b1[col], aa = a.a2[col], bb = a.ib2[col];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = mbase + i * 16 + g * 4 + e;
+                    const float u = acc[i][n][e] + bias;
+                    t2[row * S + col] = (tbase + row >= 0) ? snakebeta(u, aa, bb) : 0.0f;
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: x' = conv2(t2) + b2 + x   (+ running sum over the AMP blocks, / num_kernels)
+    mma(t2, 1, a.w2);
+    const long long ob = (long long)b * a.L;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = n * 16 + r;
+        if (col >= C) continue;
+        const float bias = a.b2[col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = mbase + i * 16 + g * 4 + e;
+                const long long t = t0 + row;
+                if (row >= TT || t >= a.L) continue;
+                const long long o = (ob + t) * C + col;
+                float v = acc[i][n][e] + bias;
+                v = v + a.x[o];                                      // x = xt + x      (models.py:119)
+                if (a.epi >= CE_RES_ACC) v = a.acc[o] + v;           // xs += resblock  (models.py:224)
+                if (a.epi == CE_RES_ACC_DIV) v = v / a.divisor;      // xs / num_kernels (models.py:225)
+                a.out[o] = v;
+            }
+    }
+}
+
+template <int C, int MT>
+static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
+    constexpr int TR = 4 * MT * 16;
+    const int TT = TR - (a.ks - 1);
+    a.tiles_per_batch = (int)((a.L + TT - 1) / TT);
+    const size_t lds = (size_t)((TR + (a.ks - 1) * a.dil) + TR + (a.ks - 1)) * (C + 2) * sizeof(float);
+    if (lds > 160 * 1024 || TT <= 0) { set_error("amp_pair tile needs %zu B of LDS", lds); return BVC_EINVAL; }
+    ProbeScope probe(PK_CONV, s);
+    hipLaunchKernelGGL((amp_pair_kernel<C, MT>), dim3((unsigned)(a.tiles_per_batch * (long long)B)), dim3(256), lds, s, a);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, long long L, float *out, int B, int epi,
+                    const float *acc, float divisor, hipStream_t s) {
+    if (B <= 0 || L <= 0) return BVC_OK;
+    if (c1.cin != c1.cout || c2.cin != c1.cin || c2.ks != c1.ks || c2.dil != 1 || !c1.act_a || !c2.act_a) {
+        set_error("amp_pair: unsupported layer pair");
+        return BVC_EINVAL;
+    }
+    AmpArgs a;
+    a.x = x; a.out = out; a.acc = acc; a.L = L;
+    a.w1 = c1.wp; a.b1 = c1.bias; a.a1 = c1.act_a; a.ib1 = c1.act_ib;
+    a.w2 = c2.wp; a.b2 = c2.bias; a.a2 = c2.act_a; a.ib2 = c2.act_ib;
+    a.divisor = divisor; a.epi = epi; a.ks = c1.ks; a.dil = c1.dil; a.tiles_per_batch = 0;
+    switch (c1.cin) {
+        case 64: return launch_amp_t<64, 1>(a, B, s);
+        case 32: return launch_amp_t<32, 2>(a, B, s);
+        case 16: return launch_amp_t<16, 2>(a, B, s);
+        case 8:  return launch_amp_t<8, 2>(a, B, s);
+        default: set_error("amp_pair: unsupported channel count %d", c1.cin); return BVC_EINVAL;
+    }
+}
+
 template <int CIN, int NTW, int MT>
 static int launch_one(const ConvArgs &a, int B, hipStream_t s) {
     constexpr int TT = 4 * MT * 16;
@@ -166,6 +352,10 @@ static int allow_big_lds() {
 
 int conv_kernels_init() {
     int rc;
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if ((rc = allow_big_lds<128, 4, 2>())) return rc;
     if ((rc = allow_big_lds<80, 4, 2>())) return rc;
     if ((rc = allow_big_lds<64, 4, 2>())) return rc;
