@@ -196,21 +196,35 @@ __global__ __launch_bounds__(256) void amp_pair_kernel(AmpArgs a) {
     const float *xb = a.x + (long long)b * a.L * C;
     const long long tbase = t0 - (ks - 1);                 // global row of local row 0 of phase 2 / t2
 
-    // ---- phase 1: activated input span
-    for (int idx = tid; idx < rows1 * C4; idx += 256) {
-        const int row = idx / C4, c4 = idx - row * C4;
-        const long long tg = tbase - halo1 + row;
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (tg >= 0 && tg < a.L) {
-            v = *reinterpret_cast<const f32x4 *>(xb + tg * C + c4 * 4);
-            const f32x4 aa = *reinterpret_cast<const f32x4 *>(a.a1 + c4 * 4);
-            const f32x4 bb = *reinterpret_cast<const f32x4 *>(a.ib1 + c4 * 4);
+    // ---- phase 1: activated input span.  All global loads of the span are issued before the first
+    // SnakeBeta is evaluated (one exposed memory round trip per workgroup instead of one per row group).
+    {
+        constexpr int NLD = ((TR + 10 * 5) * C4 + 255) / 256;       // ks <= 11, dil <= 5
+        f32x4 v[NLD];
+        const int total = rows1 * C4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = snakebeta(v[e], aa[e], bb[e]);
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / C4, c4 = idx - row * C4;
+            const long long tg = tbase - halo1 + row;
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (idx < total && tg >= 0 && tg < a.L) v[i] = *reinterpret_cast<const f32x4 *>(xb + tg * C + c4 * 4);
         }
-        float2 *dst = reinterpret_cast<float2 *>(t1 + row * S + c4 * 4);
-        dst[0] = make_float2(v[0], v[1]);
-        dst[1] = make_float2(v[2], v[3]);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < total) {
+                const int row = idx / C4, c4 = idx - row * C4;
+                const f32x4 aa = *reinterpret_cast<const f32x4 *>(a.a1 + c4 * 4);
+                const f32x4 bb = *reinterpret_cast<const f32x4 *>(a.ib1 + c4 * 4);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = snakebeta(v[i][e], aa[e], bb[e]);   // S(0) = 0 keeps the zero padding
+                float2 *dst = reinterpret_cast<float2 *>(t1 + row * S + c4 * 4);
+                dst[0] = make_float2(o[0], o[1]);
+                dst[1] = make_float2(o[2], o[3]);
+            }
+        }
     }
     for (int idx = tid; idx < (ks - 1) * S; idx += 256) t2[TR * S + idx] = 0.0f;    // spare rows read by discarded outputs
     __syncthreads();
@@ -222,29 +236,39 @@ __global__ __launch_bounds__(256) void amp_pair_kernel(AmpArgs a) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // weight fragments of chunk q+1 are fetched while chunk q feeds the MFMAs
         const float *wl = wp + lane;
-        for (int j = 0; j < ks; ++j) {
-            const float *arow = tile + (mbase + r + j * d) * S + g;
-            const float *wj = wl + (long long)j * C4 * NT * 64;
+        constexpr int CPT = C4 / CGU;                       // chunks per tap
+        const int nch = ks * CPT;
+        float bcur[CGU][NT], bnxt[CGU][NT];
+        auto loadb = [&](float (&dstb)[CGU][NT], int q) {
+            const float *wq = wl + (long long)q * CGU * NT * 64;      // packed [tap][cin/4][ntile][64] is chunk-linear
+#pragma unroll
+            for (int u = 0; u < CGU; ++u)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) dstb[u][n] = wq[(u * NT + n) * 64];
+        };
+        loadb(bcur, 0);
 #pragma unroll 1
-            for (int cg0 = 0; cg0 < C4; cg0 += CGU) {
-                float bw[CGU][NT];
+        for (int q = 0; q < nch; ++q) {
+            if (q + 1 < nch) loadb(bnxt, q + 1);
+            const int j = q / CPT, cg0 = (q - j * CPT) * CGU;
+            const float *arow = tile + (mbase + r + j * d) * S + g;
 #pragma unroll
-                for (int u = 0; u < CGU; ++u)
+            for (int u = 0; u < CGU; ++u) {
+                float av[MT];
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) bw[u][n] = wj[((cg0 + u) * NT + n) * 64];
+                for (int i = 0; i < MT; ++i) av[i] = arow[i * 16 * S + (cg0 + u) * 4];
 #pragma unroll
-                for (int u = 0; u < CGU; ++u) {
-                    float av[MT];
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) av[i] = arow[i * 16 * S + (cg0 + u) * 4];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-                            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bw[u][n], acc[i][n], 0, 0, 0);
-                }
+                    for (int n = 0; n < NT; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bcur[u][n], acc[i][n], 0, 0, 0);
             }
+#pragma unroll
+            for (int u = 0; u < CGU; ++u)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bcur[u][n] = bnxt[u][n];
         }
     };
 
