@@ -78,7 +78,9 @@ enum GemmEpi {
     EPI_ELU = 1,         // y = elu(acc + bias)
     EPI_CODE = 2,        // p = sigmoid(acc+bias); z = rint(p); masked by bits  (bvrnn.py:189-194)
     EPI_MEL = 3,         // y = acc + bias (mel frame) ; y2 = (y - mean) / std  (bvrnn.py:202-204)
-    EPI_GRU = 4          // PyTorch GRU cell, 3 gates x 2 groups
+    EPI_GRU = 4,         // PyTorch GRU cell, 3 gates x 2 groups (whole cell in one launch)
+    EPI_GRU_PART = 5     // GRU cell whose hidden part and phi_z part were pre-computed on the side branch:
+                         //   gi = acc + y2part (W_ih[:, H:] phi_z + b_ih), gh = y3part (W_hh h + b_hh)
 };
 
 struct GemmParams {
@@ -89,7 +91,8 @@ struct GemmParams {
     const float *bias0;        // group 0 bias [gates*N]
     const float *bias1;        // group 1 bias (GRU only)
     DynPtr  y, y2, y3;         // outputs (y2/y3 optional)
-    DynPtr  aux;               // CODE: bits per frame (one per row); GRU: previous h
+    DynPtr  aux;               // CODE: bits per frame (one per row); GRU: previous h; ELU: optional addend
+    const float *part_i; const float *part_h; long long ldpart;   // GRU_PART: side-branch partial sums [M][3H]
     const float *mean; const float *stdv; // MEL epilogue
     int     var_bit;
     const CallDesc *desc;      // null for stand-alone launches (all pointers static)

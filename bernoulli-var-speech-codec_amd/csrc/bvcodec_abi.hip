@@ -77,13 +77,17 @@ struct bvc_model {
     // captured recurrent steps (hipGraph), keyed by (kind, batch, workspace)
     struct StepGraph { int kind; int B; void *ws; void *probe; hipGraphExec_t exec1, execN; };
     mutable std::vector<StepGraph> graphs;
-    mutable hipStream_t cap_stream = nullptr;
+    mutable hipStream_t cap_stream = nullptr, side_stream = nullptr;
+    mutable std::vector<hipEvent_t> cap_events;
+    bool side_branch = false;   // measured SLOWER on MI355X (cross-branch graph dependencies + no spare L2->CU bandwidth): opt-in
     bool use_graph = true;
     bool fused_amp = true;
 
     ~bvc_model() {
         for (auto &g : graphs) { (void)hipGraphExecDestroy(g.exec1); (void)hipGraphExecDestroy(g.execN); }
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+        for (auto e : cap_events) (void)hipEventDestroy(e);
         for (void *p : allocs) (void)hipFree(p);
     }
 };
@@ -374,6 +378,7 @@ struct Workspace {
     float *yn, *pxA, *pxB, *pxC;
     float *step[16];            // per-step [B, max(H, ...)] scratch vectors
     float *hbuf;                // [2][B][H] GRU state ping-pong (parity of the frame counter)
+    float *part_i, *part_h, *part_d;   // side-branch partial sums: W_ih[:,H:] phi_z + b_ih, W_hh h + b_hh, dec.0[:,H:] h
     CallDesc *desc;             // per-call dynamic state read by the captured step kernels
     float *mel, *bits;          // facade-level buffers
     // vocoder
@@ -403,6 +408,9 @@ void carve(const bvc_model *m, int B, int64_t T, char *base, Workspace *w) {
     // graph captured for (B, workspace) stays valid for every T
     for (int i = 0; i < 16; ++i) w->step[i] = take(mt16 * vmax);
     w->hbuf = take(2 * mt16 * H);
+    w->part_i = take(mt16 * 3 * H);
+    w->part_h = take(mt16 * 3 * H);
+    w->part_d = take(mt16 * H);
     w->desc = reinterpret_cast<CallDesc *>(take(64));
     w->yn = take(BT * c.num_mels);
     w->pxA = take(mt16 * (size_t)T * H);                       // final phi_x / phi_z: frame-packed
@@ -455,15 +463,23 @@ GemmParams lin2_params(const Linear &l, DynPtr x1, int K1, DynPtr x2, int K2, in
     return p;
 }
 
-struct StepNode { GemmParams p; int epi; };
+// One operation of a step: a kernel on the main or the side branch, or an event record / wait that
+// forks and joins the two branches (they become graph dependencies under stream capture).
+enum { OP_KERNEL = 0, OP_RECORD = 1, OP_WAIT = 2 };
+enum { BR_MAIN = 0, BR_SIDE = 1 };
+struct StepNode { int op; int branch; int event; GemmParams p; int epi; };
 enum { STEP_ENCODE = 0, STEP_DECODE = 1 };
+enum { EV_START = 0, EV_DEC0H = 1, EV_PZ = 2, EV_GATES = 3, EV_COUNT = 4 };
 
-// The kernel sequence of ONE frame.  Every pointer is either workspace-static, frame-indexed through
+// The operation sequence of ONE frame.  Every pointer is either workspace-static, frame-indexed through
 // the call descriptor, or parity-indexed (GRU state), so the same sequence serves every frame and
 // every call: it is captured once into a hipGraph.  Internal activations are kept in MFMA fragment
 // order (packed=1) so every operand load is a coalesced 1 KiB read.
 //   encode (bvrnn.py:187-206): enc -> sigmoid/round/mask -> phi_z -> dec -> phi_x(norm) -> GRU
 //   decode (bvrnn.py:222-227): [phi_z batched over all frames beforehand] dec -> phi_x(norm) -> GRU
+// Side branch: the halves of the split dot products that do not depend on the current frame's chain -
+// dec.0[:, H:] h, W_hh h + b_hh, W_ih[:, H:] phi_z + b_ih - run concurrently with the chain (which is
+// latency-bound), so the GRU kernel on the critical path only streams W_ih[:, :H].
 std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, int kind) {
     const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
     std::vector<StepNode> plan;
@@ -475,65 +491,146 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
     float *d1 = w.step[5], *d2 = w.step[6], *d3 = w.step[7], *dn = w.step[8];
     float *g1 = w.step[9], *g2 = w.step[10], *g3 = w.step[11];
     auto S = [&](float *p, int ld) { return dp_static(p, ld, 1); };
-    DynPtr pz_final;
+    const bool side = m->side_branch;
+    int node = 0;
+    auto K = [&](int branch, GemmParams p, int epi) {
+        p.desc = w.desc; p.node = node++;
+        p.probe = g_kprobe.enabled ? g_kprobe.dev : nullptr;
+        plan.push_back(StepNode{OP_KERNEL, branch, -1, p, epi});
+    };
+    auto REC = [&](int branch, int ev) { GemmParams z; memset(&z, 0, sizeof(z)); if (side) plan.push_back(StepNode{OP_RECORD, branch, ev, z, 0}); };
+    auto WAIT = [&](int branch, int ev) { GemmParams z; memset(&z, 0, sizeof(z)); if (side) plan.push_back(StepNode{OP_WAIT, branch, ev, z, 0}); };
+    // --- side-branch kernels (plain linears into natural [B][.] partial buffers)
+    auto side_dec0h = [&]() {       // dec.0.weight[:, H:] @ h            (no bias: added on the main branch)
+        GemmParams p = lin_params(m->dec[0], h_cur, B, dp_static(w.part_d, H));
+        p.seg[0] = GemmSeg{h_cur, m->dec[0].wp + (size_t)(H / 16) * 256, 2 * H / 16, H, 0};
+        p.bias0 = nullptr;
+        K(BR_SIDE, p, EPI_LINEAR);
+    };
+    auto side_hh = [&]() {          // W_hh @ h + b_hh
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.nseg = 1;
+        p.seg[0] = GemmSeg{h_cur, m->w_hh, H / 16, H, 0};
+        p.M = B; p.N = 3 * H; p.bias0 = m->b_hh;
+        p.y = dp_static(w.part_h, 3 * H);
+        K(BR_SIDE, p, EPI_LINEAR);
+    };
+    auto side_ihz = [&](DynPtr pz) { // W_ih[:, H:] @ phi_z + b_ih
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.nseg = 1;
+        p.seg[0] = GemmSeg{pz, m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0};
+        p.M = B; p.N = 3 * H; p.bias0 = m->b_ih;
+        p.y = dp_static(w.part_i, 3 * H);
+        K(BR_SIDE, p, EPI_LINEAR);
+    };
+
+    DynPtr pz_final = (kind == STEP_ENCODE) ? S(pz3, H) : dp_frame(DS_PZ, H, 0, 1);
     if (kind == STEP_ENCODE) {
-        plan.push_back({lin2_params(m->enc[0], dp_frame(DS_PX, H, 0, 1), H, h_cur, H, B, S(e1, H)), EPI_ELU});
-        plan.push_back({lin_params(m->enc[1], S(e1, H), B, S(e2, H)), EPI_ELU});
+        K(BR_MAIN, lin2_params(m->enc[0], dp_frame(DS_PX, H, 0, 1), H, h_cur, H, B, S(e1, H)), EPI_ELU);
+        K(BR_MAIN, lin_params(m->enc[1], S(e1, H), B, S(e2, H)), EPI_ELU);
         {
             GemmParams p = lin_params(m->enc[2], S(e2, H), B, dp_frame(DS_CODES, Z));
             p.var_bit = m->cfg.var_bit;
             p.aux = dp_frame(DS_BITS, 1);
             p.y3 = dp_frame(DS_PROB, Z);
-            plan.push_back({p, EPI_CODE});
+            K(BR_MAIN, p, EPI_CODE);
         }
-        plan.push_back({lin_params(m->phi_z[0], dp_frame(DS_CODES, Z), B, S(pz1, H)), EPI_ELU});
-        plan.push_back({lin_params(m->phi_z[1], S(pz1, H), B, S(pz2, H)), EPI_ELU});
-        plan.push_back({lin_params(m->phi_z[2], S(pz2, H), B, S(pz3, H)), EPI_ELU});
-        pz_final = S(pz3, H);
-    } else {
-        pz_final = dp_frame(DS_PZ, H, 0, 1);
+        K(BR_MAIN, lin_params(m->phi_z[0], dp_frame(DS_CODES, Z), B, S(pz1, H)), EPI_ELU);
+        K(BR_MAIN, lin_params(m->phi_z[1], S(pz1, H), B, S(pz2, H)), EPI_ELU);
+        K(BR_MAIN, lin_params(m->phi_z[2], S(pz2, H), B, S(pz3, H)), EPI_ELU);
+        REC(BR_MAIN, EV_PZ);
     }
-    plan.push_back({lin2_params(m->dec[0], pz_final, H, h_cur, H, B, S(d1, H)), EPI_ELU});
-    plan.push_back({lin_params(m->dec[1], S(d1, H), B, S(d2, H)), EPI_ELU});
-    plan.push_back({lin_params(m->dec[2], S(d2, H), B, S(d3, H)), EPI_ELU});
+    const int n_dec0 = node;
+    if (side) {      // dec.0 on the critical path only sees phi_z; the h half arrives from the side branch
+        GemmParams p = lin_params(m->dec[0], pz_final, B, S(d1, H));
+        p.seg[0] = GemmSeg{pz_final, m->dec[0].wp, 2 * H / 16, H, 0};
+        p.aux = dp_static(w.part_d, H);
+        WAIT(BR_MAIN, EV_DEC0H);
+        K(BR_MAIN, p, EPI_ELU);
+    } else {
+        K(BR_MAIN, lin2_params(m->dec[0], pz_final, H, h_cur, H, B, S(d1, H)), EPI_ELU);
+    }
+    (void)n_dec0;
+    K(BR_MAIN, lin_params(m->dec[1], S(d1, H), B, S(d2, H)), EPI_ELU);
+    K(BR_MAIN, lin_params(m->dec[2], S(d2, H), B, S(d3, H)), EPI_ELU);
     {
         GemmParams p = lin_params(m->dec[3], S(d3, H), B, kind == STEP_DECODE ? dp_frame(DS_MEL, X) : dp_null());
         p.y2 = S(dn, X); p.mean = m->mean_mel; p.stdv = m->std_mel;
-        plan.push_back({p, EPI_MEL});
+        K(BR_MAIN, p, EPI_MEL);
     }
-    plan.push_back({lin_params(m->phi_x[0], S(dn, X), B, S(g1, H)), EPI_ELU});
-    plan.push_back({lin_params(m->phi_x[1], S(g1, H), B, S(g2, H)), EPI_ELU});
-    plan.push_back({lin_params(m->phi_x[2], S(g2, H), B, S(g3, H)), EPI_ELU});
+    K(BR_MAIN, lin_params(m->phi_x[0], S(dn, X), B, S(g1, H)), EPI_ELU);
+    K(BR_MAIN, lin_params(m->phi_x[1], S(g1, H), B, S(g2, H)), EPI_ELU);
+    K(BR_MAIN, lin_params(m->phi_x[2], S(g2, H), B, S(g3, H)), EPI_ELU);
     {
         GemmParams p;
         memset(&p, 0, sizeof(p));
-        p.nseg = 3;
-        p.seg[0] = GemmSeg{S(g3, H), m->w_ih, 2 * H / 16, H, 0};                       // cat([phi_x_gen, phi_z]) bvrnn.py:206
-        p.seg[1] = GemmSeg{pz_final, m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0};
-        p.seg[2] = GemmSeg{h_cur, m->w_hh, H / 16, H, 1};
         p.M = B; p.N = H; p.gate_rows = H;
-        p.bias0 = m->b_ih; p.bias1 = m->b_hh;
         p.y = h_next;
         p.y2 = (kind == STEP_ENCODE) ? dp_frame(DS_ALLH, H, 1) : dp_null();   // all_h[:, t+1] (bvrnn.py:205)
         p.aux = h_cur;
-        plan.push_back({p, EPI_GRU});
+        if (side) {
+            p.nseg = 1;
+            p.seg[0] = GemmSeg{S(g3, H), m->w_ih, 2 * H / 16, H, 0};                    // W_ih[:, :H] @ phi_x_gen
+            p.part_i = w.part_i; p.part_h = w.part_h; p.ldpart = 3LL * H;
+            WAIT(BR_MAIN, EV_GATES);
+            K(BR_MAIN, p, EPI_GRU_PART);
+        } else {
+            p.nseg = 3;
+            p.seg[0] = GemmSeg{S(g3, H), m->w_ih, 2 * H / 16, H, 0};                    // cat([phi_x_gen, phi_z]) bvrnn.py:206
+            p.seg[1] = GemmSeg{pz_final, m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0};
+            p.seg[2] = GemmSeg{h_cur, m->w_hh, H / 16, H, 1};
+            p.bias0 = m->b_ih; p.bias1 = m->b_hh;
+            K(BR_MAIN, p, EPI_GRU);
+        }
     }
-    for (size_t i = 0; i < plan.size(); ++i) {
-        plan[i].p.desc = w.desc; plan[i].p.node = (int)i;
-        plan[i].p.probe = g_kprobe.enabled ? g_kprobe.dev : nullptr;
+    if (side) {
+        // side-branch operations, inserted at the positions where their inputs exist: step start for the
+        // two h products; after phi_z for the W_ih half (encode) or step start (decode: phi_z is batched)
+        std::vector<StepNode> main_ops;
+        main_ops.swap(plan);
+        REC(BR_MAIN, EV_START);
+        WAIT(BR_SIDE, EV_START);
+        side_dec0h();
+        REC(BR_SIDE, EV_DEC0H);
+        side_hh();
+        if (kind == STEP_DECODE) { side_ihz(pz_final); REC(BR_SIDE, EV_GATES); }
+        for (const StepNode &n : main_ops) {
+            plan.push_back(n);
+            if (n.op == OP_RECORD && n.event == EV_PZ) {        // encode: phi_z ready
+                WAIT(BR_SIDE, EV_PZ);
+                side_ihz(pz_final);
+                REC(BR_SIDE, EV_GATES);
+            }
+        }
     }
     return plan;
 }
 
+int count_kernels(const std::vector<StepNode> &plan) {
+    int n = 0;
+    for (const StepNode &s : plan) n += (s.op == OP_KERNEL);
+    return n;
+}
+
 // Launch `nsteps` consecutive frames; the frame counter is advanced ONCE at the end: frame k of the
-// group runs with the static offset tstep = k baked into its kernel arguments.
-int launch_steps(const std::vector<StepNode> &plan, const Workspace &w, int nsteps, hipStream_t s) {
+// group runs with the static offset tstep = k baked into its kernel arguments.  With side == nullptr
+// everything runs in plan order on `s` (the plan order respects every dependency).
+int launch_steps(const bvc_model *m, const std::vector<StepNode> &plan, const Workspace &w, int nsteps, hipStream_t s,
+                 hipStream_t side) {
     int rc;
     for (int k = 0; k < nsteps; ++k)
         for (const StepNode &n : plan) {
-            GemmParams p = n.p;
-            p.tstep = k;
-            if ((rc = launch_gemm_skinny(p, n.epi, s))) return rc;
+            hipStream_t st = (n.branch == BR_SIDE && side) ? side : s;
+            if (n.op == OP_KERNEL) {
+                GemmParams p = n.p;
+                p.tstep = k;
+                if ((rc = launch_gemm_skinny(p, n.epi, st))) return rc;
+            } else if (side) {
+                if (n.op == OP_RECORD) BVC_HIP_TRY(hipEventRecord(m->cap_events[n.event], st));
+                else                   BVC_HIP_TRY(hipStreamWaitEvent(st, m->cap_events[n.event], 0));
+            }
         }
     return launch_step_advance(w.desc, nsteps, s);
 }
@@ -547,13 +644,19 @@ int get_step_graph(const bvc_model *m, const Workspace &w, void *ws_base, int B,
     for (const auto &g : m->graphs)
         if (g.kind == kind && g.B == B && g.ws == ws_base && g.probe == probe) { *out = &g; return BVC_OK; }
     if (!m->cap_stream) BVC_HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+    if (!m->side_stream) BVC_HIP_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+    while ((int)m->cap_events.size() < EV_COUNT) {
+        hipEvent_t e;
+        BVC_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m->cap_events.push_back(e);
+    }
     bvc_model::StepGraph sg{kind, B, ws_base, probe, nullptr, nullptr};
     for (int which = 0; which < 2; ++which) {
         hipGraph_t graph = nullptr;
         g_capturing = true;
         hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
         int rc = BVC_OK;
-        if (e == hipSuccess) rc = launch_steps(plan, w, which ? GRAPH_STEPS : 1, m->cap_stream);
+        if (e == hipSuccess) rc = launch_steps(m, plan, w, which ? GRAPH_STEPS : 1, m->cap_stream, m->side_branch ? m->side_stream : nullptr);
         hipError_t e2 = (e == hipSuccess) ? hipStreamEndCapture(m->cap_stream, &graph) : e;
         g_capturing = false;
         if (rc) return rc;
@@ -574,11 +677,12 @@ int get_step_graph(const bvc_model *m, const Workspace &w, void *ws_base, int B,
 
 int run_recurrence(const bvc_model *m, const Workspace &w, void *ws_base, int B, int64_t T, int kind, hipStream_t s) {
     const std::vector<StepNode> plan = build_step(m, w, B, kind);
+    // (begin_call was given count_kernels(build_step(...)) kernels per step)
     int rc;
     if (!m->use_graph) {
         int rc2;
         for (int64_t t = 0; t < T; ++t)
-            if ((rc2 = launch_steps(plan, w, 1, s))) return rc2;
+            if ((rc2 = launch_steps(m, plan, w, 1, s, nullptr))) return rc2;
         return BVC_OK;
     }
     const bvc_model::StepGraph *g = nullptr;
@@ -636,7 +740,7 @@ int run_encode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     d.p[DS_PX] = w.pxA; d.p[DS_CODES] = d_codes; d.p[DS_BITS] = const_cast<float *>(d_bits);
     d.p[DS_PROB] = d_prob; d.p[DS_ALLH] = d_all_h;
     d.T = T;
-    if ((rc = begin_call(m, w, d, 14, s))) return rc;
+    if ((rc = begin_call(m, w, d, count_kernels(build_step(m, w, B, STEP_ENCODE)), s))) return rc;
     if ((rc = run_recurrence(m, w, ws_base, B, T, STEP_ENCODE, s))) return rc;
     if (d_hT && (rc = read_state(w, B, H, T, d_hT, s))) return rc;
     return BVC_OK;
@@ -656,7 +760,7 @@ int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     memset(&d, 0, sizeof(d));
     d.p[DS_PZ] = w.pxA; d.p[DS_MEL] = d_mel;
     d.T = T;
-    if ((rc = begin_call(m, w, d, 8, s))) return rc;
+    if ((rc = begin_call(m, w, d, count_kernels(build_step(m, w, B, STEP_DECODE)), s))) return rc;
     if ((rc = run_recurrence(m, w, ws_base, B, T, STEP_DECODE, s))) return rc;
     if (d_hT && (rc = read_state(w, B, H, T, d_hT, s))) return rc;
     return BVC_OK;
@@ -741,6 +845,8 @@ int bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t n
     {
         const char *ng = getenv("BVC_NO_GRAPH");
         m->use_graph = !(ng && ng[0] == '1');
+        const char *sb = getenv("BVC_SIDE_BRANCH");
+        m->side_branch = (sb && sb[0] == '1');
         const char *ua = getenv("BVC_UNFUSED_AMP");
         m->fused_amp = !(ua && ua[0] == '1');
     }

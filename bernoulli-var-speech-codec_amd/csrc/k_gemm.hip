@@ -152,16 +152,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
         const int n = n0 + (tid & 15);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            bias[q] = p.bias0[(long long)q * p.gate_rows + n];
+            bias[q] = p.bias0 ? p.bias0[(long long)q * p.gate_rows + n] : 0.0f;
             if (NGRP > 1) bias[NG + q] = p.bias1[(long long)q * p.gate_rows + n];
         }
     }
 
-    f32x4 acc0[NG], acc1[NGRP > 1 ? NG : 1];
+    f32x4 acc0[NG], acc1[NG];
 #pragma unroll
     for (int q = 0; q < NG; ++q) acc0[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < (NGRP > 1 ? NG : 1); ++q) acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < NG; ++q) acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int nb = 0;
 #pragma unroll
@@ -181,10 +181,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
         if (lo < hi) {
             const long long gate_stride = (long long)(p.gate_rows >> 4) * p.seg[s].wnb * 256;
             const float *wl = p.seg[s].w + (long long)ntile * p.seg[s].wnb * 256 + lane * 4;
-            if (NGRP == 1 || p.seg[s].grp == 0)
+            if constexpr (NGRP == 1) {
                 run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
-            else
-                run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc1);
+            } else {
+                if (p.seg[s].grp == 0)
+                    run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
+                else
+                    run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc1);
+            }
         }
         base += sb;
     }
@@ -214,6 +218,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
         const Resolved y = resolve(p.y, dsc, mt16, p.tstep);
         if (epi == EPI_LINEAR || epi == EPI_ELU) {
             float o = v[0];
+            if (p.aux.base) o += p.aux.base[(long long)m * p.aux.ld + n];     // pre-computed half of a split dot product
             if (epi == EPI_ELU) o = elu1(o);
             store_out(y, m, n, o);
         } else if (epi == EPI_CODE) {
@@ -232,9 +237,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             if (y.ok) store_out(y, m, n, d);
             const Resolved y2 = resolve(p.y2, dsc, mt16, p.tstep);
             store_out(y2, m, n, (d - p.mean[n]) / p.stdv[n]);
-        } else if (NGRP > 1 && NG == 3) {                            // EPI_GRU
+        } else if (epi == EPI_GRU_PART) {
+          if constexpr (NG == 3 && NGRP == 1) {
+            // gi = W_ih [phi_x_gen ; phi_z] + b_ih with the phi_z half (+ b_ih) taken from the side branch,
+            // gh = W_hh h + b_hh entirely from the side branch.  NGRP == 1: v[0..2] hold the phi_x_gen half.
+            const long long H = p.gate_rows;
+            const float *pi = p.part_i + (long long)m * p.ldpart + n;
+            const float *ph = p.part_h + (long long)m * p.ldpart + n;
+            const float gi_r = v[0] + pi[0], gi_z = v[1] + pi[H], gi_n = v[2] + pi[2 * H];      // bias0 is null here
+            const float rg = sigmoid1(ph[0] + gi_r);
+            const float zg = sigmoid1(ph[H] + gi_z);
+            const float ng = tanhf(gi_n + rg * ph[2 * H]);
+            const Resolved hprev = resolve(p.aux, dsc, mt16, p.tstep);
+            const float hp = hprev.packed ? hprev.p[packed_off(m, n, hprev.ld)] : hprev.p[(long long)m * hprev.ld + n];
+            const float hn = (hp - ng) * zg + ng;
+            store_out(y, m, n, hn);
+            const Resolved y2 = resolve(p.y2, dsc, mt16, p.tstep);
+            if (y2.ok) store_out(y2, m, n, hn);
+          }
+        } else if (epi == EPI_GRU) {
+          if constexpr (NG == 3 && NGRP == 2) {
             const float gi_r = v[0], gi_z = v[1], gi_n = v[2];
-            const float gh_r = v[NACC > 3 ? 3 : 0], gh_z = v[NACC > 4 ? 4 : 0], gh_n = v[NACC > 5 ? 5 : 0];
+            const float gh_r = v[3], gh_z = v[4], gh_n = v[5];
             const float rg = sigmoid1(gh_r + gi_r);
             const float zg = sigmoid1(gh_z + gi_z);
             const float ng = tanhf(gi_n + rg * gh_n);
@@ -244,6 +268,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             store_out(y, m, n, hn);
             const Resolved y2 = resolve(p.y2, dsc, mt16, p.tstep);
             if (y2.ok) store_out(y2, m, n, hn);
+          }
         }
     }
     if (p.probe && tid == 0) {   // slots: [0, T*nodes) first-workgroup start, [T*nodes, 2*T*nodes) last end
@@ -282,8 +307,9 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s) {
     }
     const int n_tiles = p.N / 16, m_tiles = (p.M + 15) / 16;
     const int grid = 8 * ((n_tiles + 7) / 8) * m_tiles;
-    ProbeScope probe(epi == EPI_GRU ? PK_GRU : PK_LINEAR, s);
-    if (epi == EPI_GRU)      launch_skinny_t<3, 2, 16, 3>(p, epi, grid, s);
+    ProbeScope probe((epi == EPI_GRU || epi == EPI_GRU_PART) ? PK_GRU : PK_LINEAR, s);
+    if (epi == EPI_GRU)           launch_skinny_t<3, 2, 16, 3>(p, epi, grid, s);
+    else if (epi == EPI_GRU_PART) launch_skinny_t<3, 1, 8, 4>(p, epi, grid, s);
     else if (nb >= 128)      launch_skinny_t<1, 1, 16, 8>(p, epi, grid, s);
     else                     launch_skinny_t<1, 1, 8, 8>(p, epi, grid, s);
     BVC_HIP_TRY(hipGetLastError());

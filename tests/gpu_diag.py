@@ -154,7 +154,8 @@ def kprobe():
     codes = model.encode(x, 3000)
     _abi.check(lib.bvc_kprobe_enable(1))
     enc_names = ["enc.0 K2048", "enc.2", "enc.4 N64", "phi_z.0 K64", "phi_z.2", "phi_z.4", "dec.0 K2048", "dec.2",
-                 "dec.4", "dec.6 N80", "phi_x.0 K80", "phi_x.2", "phi_x.4", "GRU"]
+                 "dec.4", "dec.6 N80", "phi_x.0 K80", "phi_x.2", "phi_x.4", "GRU", "side dec0h", "side W_hh h",
+                 "side W_ih phi_z"]
     dec_names = enc_names[6:]
 
     def dump(names):
