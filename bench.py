@@ -40,7 +40,7 @@ SECONDS = 5.0
 BITRATE = 3000
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix = vector peak
 PROBE_NAMES = {1: "gemm_skinny_kernel<1,1,*> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<3,2,16,3> (GRU cell)",
-               3: "conv_mfma_kernel (BigVGAN conv)", 4: "gemm_batched_kernel (phi_x / phi_z over all frames)",
+               3: "amp_pair_kernel / conv_mfma_kernel (BigVGAN convs)", 4: "gemm_batched_kernel (phi_x / phi_z over all frames)",
                5: "stft_logmel_kernel", 6: "conv_post_kernel"}
 
 
@@ -63,7 +63,7 @@ def flops_per_step(conf, B, T):
     return {
         1: (2.0 * BT * (enc_lin + dec_lin), T * (13 + 10)),
         2: (2.0 * BT * 2 * gru, 2 * T),
-        3: (2.0 * BT * voc, 1 + len(v["upsample_rates"]) * (1 + 18)),
+        3: (2.0 * BT * voc, 1 + len(v["upsample_rates"]) * (1 + 9)),      # conv_pre + per stage: ConvT + 9 fused AMP iterations
         4: (2.0 * BT * phix, 3),
         5: (2.0 * BT * 5 * 512 * 9 * 1.0, 1),
         6: (2.0 * BT * post, 1),
