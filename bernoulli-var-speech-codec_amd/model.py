@@ -165,6 +165,25 @@ class BVRNN(_OnDevice):
         return codes.to(out_dev), all_h.to(out_dev)
 
     @torch.no_grad()
+    def encode_stateful(self, y, varBitrate, h):
+        """Like encode() but returns the state AFTER the last frame instead of the per-frame states:
+        (codes (B,T,z), h_next (1,B,h_dim)).  This is what chunked / streaming encoding needs (the
+        reference's encode() only exposes the state before each frame, bvrnn.py:205,209)."""
+        eng = self.engine(y)
+        out_dev = y.device
+        y = _prep(y, eng.device)
+        B, T, _ = y.shape
+        bits = _prep(varBitrate, eng.device) if varBitrate is not None else None
+        h0 = _prep(h.reshape(B, self.h_dim), eng.device)
+        codes = torch.empty(B, T, self.z_dim, device=eng.device)
+        hT = torch.empty(B, self.h_dim, device=eng.device)
+        ws, nws = eng.workspace(B, T)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.lib.bvc_bvrnn_encode(eng.handle, _abi.ptr(y), _abi.ptr(bits), _abi.ptr(h0), B, T,
+                                                _abi.ptr(codes), None, _abi.ptr(hT), None, ws, nws, eng.stream()))
+        return codes.to(out_dev), hT.unsqueeze(0).to(out_dev)
+
+    @torch.no_grad()
     def decode(self, z, h):
         """z (B,T,z_dim), h (1,B,h_dim) -> (mel (B,T,x_dim), h (1,B,h_dim))."""
         eng = self.engine(z)

@@ -1,0 +1,113 @@
+"""Stateful chunked (streaming) encode / decode on top of the same kernels (SURVEY.md 8f rank 1,
+BASELINE.json configs[4]).
+
+The reference facade has no streaming mode: it zero-initialises the GRU state on every call
+(bvrnn_codec_model.py:60,69) and never returns the state after the last frame (bvrnn.py:205).  The
+primitives are causal, though, so chunked processing is exact:
+
+* front-end: frame t reads samples [256t-256, 256t+768) -> it is emitted as soon as those samples
+  have arrived (algorithmic look-ahead 768 samples = 34.8 ms, README.md:19); the last frames of an
+  utterance, which need the right reflect padding, are emitted by ``flush()``;
+* BVRNN: the GRU state is carried from chunk to chunk (``bvc_bvrnn_encode/decode`` take h0, return hT);
+* vocoder: every output sample depends on at most ``CONTEXT_FRAMES`` past mel frames (conv_pre 6 frames
+  + per stage 12*(k-1) = 120 samples of AMP halo + 1 sample of transposed conv), so each hop re-runs
+  the generator over [context | new frames] and keeps the new samples.  (A ring-buffer vocoder that
+  avoids recomputing the context is future work.)
+
+``tests/test_gpu_streaming.py`` checks that any chunking reproduces the offline encode()/decode().
+"""
+import math
+
+import torch
+
+from .model import SCALING
+
+CONTEXT_FRAMES = 26      # ceil(6 + 1 + 15 + 1/8 + 120/64 + 1/64 + 120/128 + 1/128 + 120/256 + 6/256)
+
+
+class StreamingEncoder:
+    def __init__(self, model, batch, bitrate, device=None):
+        self.m = model
+        self.B = batch
+        self.bits = model.bits_per_frame(bitrate)
+        eng = model.engine(None if device is None else torch.empty(0, device=device))
+        self.dev = eng.device
+        c = model.conf
+        self.hop, self.win, self.pl = c["hopsize"], c["winsize"], c["mel_pad_left"]
+        self.h = torch.zeros(1, batch, c["h_dim"], device=self.dev)
+        self.buf = torch.empty(batch, 0, device=self.dev)      # samples from index self.s0 on
+        self.s0 = 0                                            # global index of buf[:, 0] (multiple of hop)
+        self.n = 0                                             # samples received
+        self.frames = 0                                        # frames emitted
+
+    def _emit(self, upto, total_len=None):
+        """Encode frames [self.frames, upto); total_len: utterance length when flushing."""
+        k = upto - self.frames
+        if k <= 0:
+            return torch.empty(self.B, 0, self.m.conf["z_dim"], device=self.dev)
+        mel = self.m.mel_spectrogram(self.buf)                 # local frames; reflect pads only matter at the ends
+        f0 = self.frames - self.s0 // self.hop
+        mel = mel[:, f0:f0 + k].contiguous()
+        bits = torch.full((self.B, k), self.bits, device=self.dev)
+        codes, self.h = self.m.bvrnn.encode_stateful(mel, bits, self.h)
+        self.frames = upto
+        # keep what later frames still read: from sample hop*frames - 2*hop (so the next frame is local frame 2)
+        keep_from = max(0, self.hop * self.frames - 2 * self.hop)
+        if keep_from > self.s0:
+            self.buf = self.buf[:, keep_from - self.s0:].contiguous()
+            self.s0 = keep_from
+        return codes
+
+    @torch.no_grad()
+    def push(self, x):
+        """x (B, n) new samples -> codes (B, k, z_dim) of the frames completed by them (k may be 0)."""
+        x = x.to(self.dev, torch.float32)
+        self.buf = torch.cat([self.buf, x], 1)
+        self.n += x.shape[1]
+        pr = self.win - self.pl - self.hop                     # right look-ahead beyond the hop (512)
+        complete = 0 if self.n < self.hop + pr else (self.n - self.hop - pr) // self.hop + 1
+        if self.buf.shape[1] <= 2 * self.hop:                  # the front-end kernel needs L > 512
+            complete = self.frames
+        return self._emit(complete)
+
+    @torch.no_grad()
+    def flush(self):
+        """End of utterance: the remaining floor(L/hop) - emitted frames (right reflect padding)."""
+        total = self.n // self.hop
+        if self.buf.shape[1] <= 2 * self.hop and total > self.frames:
+            raise RuntimeError("utterance too short for the reflect padding of the STFT front-end")
+        return self._emit(total)
+
+
+class StreamingDecoder:
+    def __init__(self, model, batch, device=None):
+        self.m = model
+        self.B = batch
+        eng = model.engine(None if device is None else torch.empty(0, device=device))
+        self.dev = eng.device
+        c = model.conf
+        self.h = torch.zeros(1, batch, c["h_dim"], device=self.dev)
+        self.ctx = torch.empty(batch, 0, c["num_mels"], device=self.dev)     # last CONTEXT_FRAMES mel frames
+        self.spf = math.prod(c["vocoder_config"]["upsample_rates"])         # samples per frame (256)
+        self.tail = None
+
+    @torch.no_grad()
+    def push(self, codes):
+        """codes (B, k, z_dim) -> wav (B, 256*k): the samples of exactly those frames."""
+        k = codes.shape[1]
+        if k == 0:
+            return torch.empty(self.B, 0, device=self.dev)
+        mel, self.h = self.m.bvrnn.decode(codes.to(self.dev, torch.float32), self.h)
+        allmel = torch.cat([self.ctx, mel], 1)
+        nctx = self.ctx.shape[1]
+        wav = self.m.vocoder(allmel, 10 ** 12, _scale_div=SCALING, _time_major=True)[:, 0]
+        out = wav[:, self.spf * nctx: self.spf * (nctx + k)]
+        self.tail = wav[:, self.spf * (nctx + k):]             # partial sums beyond the last frame (models.py:238)
+        self.ctx = allmel[:, -CONTEXT_FRAMES:].contiguous()
+        return out
+
+    def flush(self, n_extra):
+        """Up to 294 samples beyond the last full frame (what decode(codes, length) returns past 256*T)."""
+        if self.tail is None:
+            return torch.empty(self.B, 0, device=self.dev)
+        return self.tail[:, :max(0, n_extra)]
