@@ -135,6 +135,9 @@ struct FrontendTables {          // device pointers
 int launch_stft_logmel(const FrontendTables &t, const float *wav, int B, long long L, long long T,
                        int pad_left, float scale, float *mel, hipStream_t s);
 
+int launch_pack_codes(const float *codes, long long frames, int z, int nbits, unsigned char *out, hipStream_t s);
+int launch_unpack_codes(const unsigned char *in, long long frames, int z, int nbits, float *codes, hipStream_t s);
+
 // ------------------------------------------------------------------ vocoder (k_vocoder.hip)
 struct ConvLayer {               // one causal conv as implicit GEMM on fp32 MFMA
     int cin;                     // input channels (multiple of 4)

@@ -973,6 +973,22 @@ int bvc_probe_end(double *mean_us, double *min_us, int32_t *n_samples) {
     return BVC_OK;
 }
 
+int bvc_pack_codes(const float *d_codes, int32_t B, int64_t T, int32_t z_dim, int32_t nbits, uint8_t *d_bytes, void *stream) {
+    if (!d_codes || !d_bytes || B <= 0 || T <= 0 || z_dim <= 0 || nbits < 0 || nbits > z_dim) {
+        set_error("bvc_pack_codes: bad arguments");
+        return BVC_EINVAL;
+    }
+    return launch_pack_codes(d_codes, (long long)B * T, z_dim, nbits, d_bytes, (hipStream_t)stream);
+}
+
+int bvc_unpack_codes(const uint8_t *d_bytes, int32_t B, int64_t T, int32_t z_dim, int32_t nbits, float *d_codes, void *stream) {
+    if (!d_codes || (!d_bytes && nbits > 0) || B <= 0 || T <= 0 || z_dim <= 0 || nbits < 0 || nbits > z_dim) {
+        set_error("bvc_unpack_codes: bad arguments");
+        return BVC_EINVAL;
+    }
+    return launch_unpack_codes(d_bytes, (long long)B * T, z_dim, nbits, d_codes, (hipStream_t)stream);
+}
+
 int bvc_kprobe_enable(int32_t on) {
     if (on && !g_kprobe.dev) {
         const size_t cap = (size_t)2 * 16 * 4096;               // up to 4096 frames x 16 nodes

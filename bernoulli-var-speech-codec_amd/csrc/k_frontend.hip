@@ -147,6 +147,54 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(FrontendTables t, cons
     }
 }
 
+// ---- wire format of the codes (the reference keeps codes as float32 {0,1,0.5})
+// frame = ceil(nbits/8) bytes, bit i of the frame at byte i/8, position i%8 (LSB first); only the
+// nbits active bits of a frame are transmitted, the masked ones (0.5) are re-created on unpack.
+__global__ void pack_codes_kernel(const float *__restrict__ codes, long long frames, int z, int nbits, int nbytes,
+                                  unsigned char *__restrict__ out) {
+    const long long total = frames * nbytes;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long f = i / nbytes;
+        const int j = (int)(i - f * nbytes);
+        unsigned v = 0;
+        for (int b = 0; b < 8; ++b) {
+            const int bit = j * 8 + b;
+            if (bit < nbits && codes[f * z + bit] > 0.75f) v |= 1u << b;
+        }
+        out[i] = (unsigned char)v;
+    }
+}
+
+__global__ void unpack_codes_kernel(const unsigned char *__restrict__ in, long long frames, int z, int nbits, int nbytes,
+                                    float *__restrict__ codes) {
+    const long long total = frames * z;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long f = i / z;
+        const int bit = (int)(i - f * z);
+        codes[i] = bit < nbits ? (float)((in[f * nbytes + (bit >> 3)] >> (bit & 7)) & 1u) : 0.5f;
+    }
+}
+
+int launch_pack_codes(const float *codes, long long frames, int z, int nbits, unsigned char *out, hipStream_t s) {
+    const int nbytes = (nbits + 7) / 8;
+    const long long total = frames * nbytes;
+    if (total <= 0) return BVC_OK;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_codes_kernel, dim3(grid), dim3(256), 0, s, codes, frames, z, nbits, nbytes, out);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_unpack_codes(const unsigned char *in, long long frames, int z, int nbits, float *codes, hipStream_t s) {
+    const int nbytes = (nbits + 7) / 8;
+    const long long total = frames * z;
+    if (total <= 0) return BVC_OK;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(unpack_codes_kernel, dim3(grid), dim3(256), 0, s, in, frames, z, nbits, nbytes, codes);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
 int launch_stft_logmel(const FrontendTables &t, const float *wav, int B, long long L, long long T,
                        int pad_left, float scale, float *mel, hipStream_t s) {
     const long long nframes = (long long)B * T;

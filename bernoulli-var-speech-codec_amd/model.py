@@ -308,3 +308,38 @@ class BVRNNCodecModel(_OnDevice):
         length = x.shape[1]
         codes = self.encode(x, bitrate)
         return self.decode(codes, length)
+
+    # ---- wire format (not in the reference, which has no bit stream: SURVEY.md 8f rank 2)
+    def active_bits(self, bitrate):
+        z = self.conf["z_dim"]
+        return z if not self.conf["var_bit"] else int(min(z, max(0.0, self.bits_per_frame(bitrate))))
+
+    @torch.no_grad()
+    def pack(self, codes, bitrate):
+        """codes (B,T,z_dim) from encode(x, bitrate) -> uint8 (B,T,ceil(n/8)), n active bits per frame."""
+        eng = self.engine(codes)
+        out_dev = codes.device
+        codes = _prep(codes, eng.device)
+        B, T, Z = codes.shape
+        n = self.active_bits(bitrate)
+        out = torch.empty(B, T, (n + 7) // 8, dtype=torch.uint8, device=eng.device)
+        if out.numel():
+            with torch.cuda.device(eng.device):
+                _abi.check(eng.lib.bvc_pack_codes(_abi.ptr(codes), B, T, Z, n, ctypes.c_void_p(out.data_ptr()),
+                                                  eng.stream()))
+        return out.to(out_dev)
+
+    @torch.no_grad()
+    def unpack(self, packed, bitrate):
+        """Inverse of pack(): uint8 (B,T,ceil(n/8)) -> float32 codes (B,T,z_dim) with 0.5 in masked positions."""
+        eng = self.engine(packed)
+        out_dev = packed.device
+        packed = packed.to(eng.device).contiguous()
+        B, T, _ = packed.shape
+        n = self.active_bits(bitrate)
+        Z = self.conf["z_dim"]
+        codes = torch.empty(B, T, Z, device=eng.device)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.lib.bvc_unpack_codes(ctypes.c_void_p(packed.data_ptr()) if packed.numel() else None, B, T, Z,
+                                                n, _abi.ptr(codes), eng.stream()))
+        return codes.to(out_dev)

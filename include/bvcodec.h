@@ -125,6 +125,15 @@ int bvc_encode(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, flo
 int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, int64_t length,
                float out_scale_div, float *d_wav, void *d_ws, size_t ws_bytes, void *stream);
 
+/* Wire format for the codes (new: the reference keeps them as float32 {0,1,0.5}, bvrnn.py:191-196, and
+ * defines no bit stream).  A frame is ceil(nbits/8) bytes, bit i at byte i/8 position i%8 (LSB first);
+ * nbits = min(z_dim, bits per frame) active bits are kept, the masked ones (0.5) are re-created on
+ * unpack.  d_bytes (B, T, ceil(nbits/8)) uint8; unpack(pack(codes)) == codes for codes from encode(). */
+int bvc_pack_codes(const float *d_codes, int32_t B, int64_t T, int32_t z_dim, int32_t nbits, uint8_t *d_bytes,
+                   void *stream);
+int bvc_unpack_codes(const uint8_t *d_bytes, int32_t B, int64_t T, int32_t z_dim, int32_t nbits, float *d_codes,
+                     void *stream);
+
 /* ---- building blocks exported for the parity tests (tests/ only; same kernels the path uses) */
 /* y[M,N] = act(x[M,K] @ w[N,K]^T + bias), act: 0 none, 1 ELU.  Recurrent-step kernel. */
 int bvc_test_linear(const float *d_x, const float *d_w, const float *d_bias, int32_t M, int32_t N,

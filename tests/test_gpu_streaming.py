@@ -60,3 +60,21 @@ def test_streaming_hop_latency_is_real_time(model):
     print(f"p50 per-hop latency for 256 streams: {p50:.2f} ms")
     assert torch.isfinite(w).all()
     assert p50 < 20.0
+
+
+@pytest.mark.parametrize("bitrate,nbytes", [(3000, 5), (1500, 3), (6000, 8), (700, 1)])
+def test_wire_format_roundtrip(model, bitrate, nbytes):
+    from bvcodec import synth
+    x = synth.synthetic_speech(2, 256 * 20 + 5, seed=4, kind="speech").to(DEV)
+    codes = model.encode(x, bitrate)
+    packed = model.pack(codes, bitrate)
+    assert packed.dtype == torch.uint8 and packed.shape == (2, 20, nbytes)
+    assert torch.equal(model.unpack(packed, bitrate), codes)
+    # reference bit order: LSB first within a byte
+    n = model.active_bits(bitrate)
+    bits = (codes[:, :, :n].cpu().numpy() > 0.75).astype(np.uint8)
+    pad = np.zeros((2, 20, nbytes * 8 - n), np.uint8)
+    ref = np.packbits(np.concatenate([bits, pad], 2), axis=2, bitorder="little")
+    assert np.array_equal(packed.cpu().numpy(), ref)
+    # payload rate: 86.13 frames/s * nbytes * 8 bit
+    assert abs(nbytes * 8 * 22050 / 256 - bitrate) < 8 * 86.2 or bitrate > 5512
