@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=SECONDS)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the K steps are issued on round-robin (independent batches overlap)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
