@@ -90,7 +90,7 @@ def cpu_baseline(conf):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=SECONDS)
@@ -114,26 +114,28 @@ def main():
     B = a.batch
     x = synth.synthetic_speech(B, L, seed=rank, kind="noise").to(device)      # resident before timing
     use_pg = torch.distributed.is_available() and torch.distributed.is_initialized()
-    gathered = torch.empty(world * B, L, device=device) if (use_pg and not a.no_gather) else None
+    nstreams = max(1, a.streams)
+    gathered = ([torch.empty(world * B, L, device=device) for _ in range(nstreams)]
+                if (use_pg and not a.no_gather) else None)
 
-    def step():
+    def step(slot=0):
         codes = model.encode(x, BITRATE)
         wav = model.decode(codes, L)
-        if gathered is not None:
-            torch.distributed.all_gather_into_tensor(gathered, wav)
+        if gathered is not None:                  # the "final gather" of the north star: one RCCL collective
+            torch.distributed.all_gather_into_tensor(gathered[slot], wav)
         return codes, wav
 
     # Steps are independent batches: issue them round-robin on `--streams` HIP streams so that the
     # latency-bound recurrent chain of one batch overlaps the next batch's work (every step still
     # runs the full encode -> decode; all K steps complete inside the timed bracket).
-    streams = [torch.cuda.Stream(device) for _ in range(max(1, a.streams))]
+    streams = [torch.cuda.Stream(device) for _ in range(nstreams)]
 
     def run(n):
         last = None
         for k in range(n):
             st = streams[k % len(streams)]
             with torch.cuda.stream(st):
-                last = step()
+                last = step(k % len(streams))
         for st in streams:
             torch.cuda.current_stream(device).wait_stream(st)
         return last

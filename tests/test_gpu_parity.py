@@ -306,3 +306,72 @@ def test_full_size_config_roundtrip_properties():
     ref_wav = oc.decode(got, 22050)
     w = model.decode(got.to(DEV), 22050).cpu()
     assert float((w - ref_wav).pow(2).mean().sqrt()) < 1e-4
+
+
+# ----------------------------------------------------------------------------------- BASELINE configs / edge cases
+def test_config0_single_10s_utterance_fixed_64bit():
+    """BASELINE configs[0]: one 10 s utterance, config_64bit (bitrate ignored), against the oracle."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    from oracle import codec as ocodec
+    model, conf, vr, ge = make_model(False, 1024)
+    x = synth.synthetic_speech(1, 220500, seed=31, kind="speech")
+    codes = model.encode(x.to(DEV), 1234).cpu()
+    assert codes.shape == (1, 861, 64) and set(torch.unique(codes).tolist()) <= {0.0, 1.0}
+    oc = ocodec.OracleCodec(conf, vr, ge)
+    r = oc.encode(x, 1234, full=True)
+    diff = codes != r["codes"]
+    if diff.any():                                   # only a tie of the reference arithmetic may differ
+        t0 = int(diff[0].any(dim=1).nonzero()[0])
+        assert ((r["prob"][0, t0][diff[0, t0]] - 0.5).abs() < 1e-5).all()
+    wav = model.decode(codes.to(DEV), 220500).cpu()
+    ref = oc.decode(codes, 220500)
+    assert wav.shape == (1, 220500)
+    assert float((wav - ref).pow(2).mean().sqrt()) < 1e-4
+
+
+@pytest.mark.parametrize("B,L", [(1, 513), (1, 767), (5, 768), (17, 1030), (33, 2049)])
+def test_short_and_ragged_shapes_vs_oracle(env, B, L):
+    """Shortest legal inputs (reflect pad needs L > 512), batch sizes that are not multiples of the
+    16-row MFMA tile, lengths that are not multiples of the hop."""
+    from bvcodec import synth
+    from oracle import codec as ocodec
+    model, conf, vr, ge = env
+    x = synth.synthetic_speech(B, L, seed=B + L, kind="noise")
+    codes = model.encode(x.to(DEV), 3000).cpu()
+    T = L // 256
+    assert codes.shape == (B, T, 64)
+    oc = ocodec.OracleCodec(conf, vr, ge)
+    r = oc.encode(x, 3000, full=True)
+    diff = codes != r["codes"]
+    assert not bool((diff & ((r["prob"] - 0.5).abs() > 1e-5)).any())
+    wav = model.decode(r["codes"].to(DEV), L).cpu()
+    ref = oc.decode(r["codes"], L)
+    assert wav.shape == ref.shape == (B, min(L, 256 * T + 294))
+    assert float((wav - ref).pow(2).mean().sqrt()) < 1e-5
+
+
+def test_bitrate_extremes(env):
+    model = env[0]
+    from bvcodec import synth
+    x = synth.synthetic_speech(2, 256 * 12, seed=2, kind="speech").to(DEV)
+    c0 = model.encode(x, 0)
+    assert (c0 == 0.5).all()                                          # 0 active bits: every position masked
+    c_hi = model.encode(x, 10 ** 6)
+    assert (c_hi != 0.5).all()                                        # saturates at z_dim bits
+    assert torch.equal(c_hi, model.encode(x, 5512.5))
+    w = model.decode(c0, 256 * 12)
+    assert torch.isfinite(w).all()
+
+
+def test_nonzero_initial_state_and_returned_state(env):
+    """BVRNN.decode(z, h) with a non-zero h (reference signature, bvrnn.py:211) against the oracle."""
+    from oracle import bvrnn as obv
+    model, conf, vr, _ = env
+    rng = np.random.default_rng(12)
+    z = torch.from_numpy(rng.integers(0, 2, size=(4, 9, 64)).astype(np.float32))
+    h0 = torch.from_numpy((0.3 * rng.standard_normal((4, 1024))).astype(np.float32))
+    mel, hT = model.bvrnn.decode(z.to(DEV), h0.unsqueeze(0).to(DEV))
+    r = obv.decode(vr, z, h0)
+    assert np.abs(mel.cpu().numpy() - r["mel"].numpy()).max() < 5e-5
+    assert np.abs(hT[0].cpu().numpy() - r["h_last"].numpy()).max() < 5e-6
