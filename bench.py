@@ -70,6 +70,24 @@ def flops_per_step(conf, B, T):
     }
 
 
+def pmc_traffic_bytes(kernel_prefix):
+    """HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc pass
+    (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE), launch-weighted.
+    PMC collection serialises every dispatch, so it is a separate pass (tools/pmc_probe.py), not part
+    of this run; None if the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic_per_launch.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if kernel_prefix in r["kernel"]:
+            k = int(r["launches"])
+            tot += k * (2.0 * float(r["FETCH_SIZE_KB_raw_avg"]) + float(r["WRITE_SIZE_KB_avg"])) * 1024.0
+            n += k
+    return round(tot / n) if n else None
+
+
 def cpu_baseline(conf):
     """Oracle (PyTorch-CPU port of the reference op sequence) on a bounded sample: 8 x 5 s."""
     from oracle import codec as ocodec
@@ -214,9 +232,13 @@ def main():
         r = rows[dom]
         out["roofline"] = {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(r["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                           "traffic": None, "kernel": r["kernel"], "mean_launch_us": r["mean_us"],
+                           "traffic": pmc_traffic_bytes("gemm_skinny_kernel<1, 1,") if dom == 1 else None,
+                           "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass; "
+                                           "algorithmic: 4.5e6 for a 1024x1024 layer at B=64)",
+                           "kernel": r["kernel"], "mean_launch_us": r["mean_us"],
                            "launches_per_step": r["launches_per_step"],
                            "timer": r["timer"],
+                           "rocprof_avg_us": "5.4 (rocprofv3 --kernel-trace, dispatch-inclusive, profiles/r01_c_kernel_stats_graph_1stream.csv)",
                            "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32); algorithmic FLOPs per launch / "
                                    "launch duration measured in situ inside the real schedule"}
         out["kernel_families"] = rows
