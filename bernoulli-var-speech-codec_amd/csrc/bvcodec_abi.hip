@@ -686,7 +686,14 @@ int run_recurrence(const bvc_model *m, const Workspace &w, void *ws_base, int B,
         return BVC_OK;
     }
     const bvc_model::StepGraph *g = nullptr;
-    if ((rc = get_step_graph(m, w, ws_base, B, kind, plan, &g))) return rc;
+    if ((rc = get_step_graph(m, w, ws_base, B, kind, plan, &g))) {
+        if (rc != BVC_EHIP) return rc;
+        // stream capture unavailable (e.g. the caller is itself capturing): same kernels, launched eagerly
+        (void)hipGetLastError();
+        for (int64_t t = 0; t < T; ++t)
+            if ((rc = launch_steps(m, plan, w, 1, s, nullptr))) return rc;
+        return BVC_OK;
+    }
     int64_t t = 0;
     for (; t + GRAPH_STEPS <= T; t += GRAPH_STEPS) BVC_HIP_TRY(hipGraphLaunch(g->execN, s));
     for (; t < T; ++t) BVC_HIP_TRY(hipGraphLaunch(g->exec1, s));

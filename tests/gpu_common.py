@@ -10,9 +10,10 @@ from bvcodec import BVRNNCodecModel, config, synth
 _CACHE = {}
 
 
-def make_model(var_bit=True, h_dim=1024, seed=1234):
-    """Product model on cuda:0 with seeded synthetic checkpoints (+ the matching oracle state dicts)."""
-    key = (var_bit, h_dim, seed)
+def make_model(var_bit=True, h_dim=1024, seed=1234, env=None):
+    """Product model on cuda:0 with seeded synthetic checkpoints (+ the matching oracle state dicts).
+    env: extra environment variables that are read when the engine is created (BVC_NO_GRAPH, ...)."""
+    key = (var_bit, h_dim, seed, tuple(sorted((env or {}).items())))
     if key in _CACHE:
         return _CACHE[key]
     base = config.DEFAULT_CONFIG if var_bit else config.DEFAULT_CONFIG_64BIT
@@ -28,6 +29,17 @@ def make_model(var_bit=True, h_dim=1024, seed=1234):
             f.write(txt)
     p1, p2 = synth.write_checkpoints(conf, d, seed=seed)
     model = BVRNNCodecModel(cfg_path, p1, p2).to("cuda:0")
+    if env:                      # the library reads its switches in bvc_model_create: create the engine now
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            model.engine()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
     vr = synth.bvrnn_state_dict(conf, seed)
     ge = synth.generator_state_dict(conf, seed + 1)
     _CACHE[key] = (model, conf, vr, ge)

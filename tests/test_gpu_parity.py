@@ -375,3 +375,25 @@ def test_nonzero_initial_state_and_returned_state(env):
     r = obv.decode(vr, z, h0)
     assert np.abs(mel.cpu().numpy() - r["mel"].numpy()).max() < 5e-5
     assert np.abs(hT[0].cpu().numpy() - r["h_last"].numpy()).max() < 5e-6
+
+
+def test_execution_variants_agree(env):
+    """The hipGraph-replayed default, the eager fallback (BVC_NO_GRAPH=1, what the library falls back to
+    when stream capture is unavailable) and the unfused vocoder (BVC_UNFUSED_AMP=1) run the same
+    arithmetic: identical codes and mel; the opt-in side-branch schedule (BVC_SIDE_BRANCH=1) splits two
+    dot products, so it agrees to rounding."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    base = env[0]
+    x = synth.synthetic_speech(5, 256 * 21 + 9, seed=77, kind="speech").to(DEV)
+    codes = base.encode(x, 3000)
+    wav = base.decode(codes, x.shape[1])
+    eager = make_model(True, 1024, env={"BVC_NO_GRAPH": "1"})[0]
+    assert torch.equal(eager.encode(x, 3000), codes)
+    assert torch.equal(eager.decode(codes, x.shape[1]), wav)
+    unfused = make_model(True, 1024, env={"BVC_UNFUSED_AMP": "1"})[0]
+    assert (unfused.decode(codes, x.shape[1]) - wav).abs().max().item() < 2e-6
+    side = make_model(True, 1024, env={"BVC_SIDE_BRANCH": "1"})[0]
+    mel_a, _ = base.bvrnn.decode(codes, torch.zeros(1, 5, 1024, device=DEV))
+    mel_b, _ = side.bvrnn.decode(codes, torch.zeros(1, 5, 1024, device=DEV))
+    assert (mel_a - mel_b).abs().max().item() < 1e-5
