@@ -135,6 +135,9 @@ struct FrontendTables {          // device pointers
 int launch_stft_logmel(const FrontendTables &t, const float *wav, int B, long long L, long long T,
                        int pad_left, float scale, float *mel, hipStream_t s);
 
+int launch_resample_poly(const float *x, int B, long long Lin, const double *h, int ntaps, int up, int down,
+                         long long n_pre_remove, float *y, long long n_out, hipStream_t s);
+int launch_peak_normalize(float *x, int B, long long L, hipStream_t s);
 int launch_pack_codes(const float *codes, long long frames, int z, int nbits, unsigned char *out, hipStream_t s);
 int launch_unpack_codes(const unsigned char *in, long long frames, int z, int nbits, float *codes, hipStream_t s);
 

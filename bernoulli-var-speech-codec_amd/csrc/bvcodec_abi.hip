@@ -980,6 +980,20 @@ int bvc_probe_end(double *mean_us, double *min_us, int32_t *n_samples) {
     return BVC_OK;
 }
 
+int bvc_resample_poly(const float *d_x, int32_t B, int64_t L_in, const double *d_h, int32_t ntaps, int32_t up, int32_t down,
+                      int64_t n_pre_remove, float *d_y, int64_t n_out, void *stream) {
+    if (!d_x || !d_h || !d_y || B <= 0 || L_in <= 0 || ntaps <= 0 || up < 1 || down < 1 || n_pre_remove < 0 || n_out <= 0) {
+        set_error("bvc_resample_poly: bad arguments");
+        return BVC_EINVAL;
+    }
+    return launch_resample_poly(d_x, B, L_in, d_h, ntaps, up, down, n_pre_remove, d_y, n_out, (hipStream_t)stream);
+}
+
+int bvc_peak_normalize(float *d_x, int32_t B, int64_t L, void *stream) {
+    if (!d_x || B <= 0 || L <= 0) { set_error("bvc_peak_normalize: bad arguments"); return BVC_EINVAL; }
+    return launch_peak_normalize(d_x, B, L, (hipStream_t)stream);
+}
+
 int bvc_pack_codes(const float *d_codes, int32_t B, int64_t T, int32_t z_dim, int32_t nbits, uint8_t *d_bytes, void *stream) {
     if (!d_codes || !d_bytes || B <= 0 || T <= 0 || z_dim <= 0 || nbits < 0 || nbits > z_dim) {
         set_error("bvc_pack_codes: bad arguments");

@@ -195,6 +195,57 @@ int launch_unpack_codes(const unsigned char *in, long long frames, int z, int nb
     return BVC_OK;
 }
 
+// ---- pre-processing of example.py:15-17: rational-rate polyphase resampling
+// (scipy.signal.resample_poly = upfirdn with a Kaiser-windowed sinc, zero padding at the edges) and
+// per-utterance peak normalisation.  One thread per output sample walks the ~len(h)/up taps of its
+// phase; accumulation in double, like the float64 reference call.
+__global__ void resample_poly_kernel(const float *__restrict__ x, long long Lin, const double *__restrict__ h, int ntaps,
+                                     int up, int down, long long n_pre_remove, float *__restrict__ y, long long n_out) {
+    const long long b = blockIdx.y;
+    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < n_out; m += (long long)gridDim.x * blockDim.x) {
+        const long long pos = (m + n_pre_remove) * down;          // index into the zero-stuffed, up-sampled signal
+        long long i = pos / up;                                   // newest input sample under the filter
+        int k = (int)(pos - i * up);                              // its tap (polyphase component)
+        if (i >= Lin) { const long long skip = i - (Lin - 1); i -= skip; k += (int)(skip * up); }
+        double acc = 0.0;
+        for (; k < ntaps && i >= 0; k += up, --i) acc += h[k] * (double)x[b * Lin + i];
+        y[b * n_out + m] = (float)acc;
+    }
+}
+
+int launch_resample_poly(const float *x, int B, long long Lin, const double *h, int ntaps, int up, int down,
+                         long long n_pre_remove, float *y, long long n_out, hipStream_t s) {
+    if (B <= 0 || n_out <= 0) return BVC_OK;
+    const int gx = (int)((n_out + 255) / 256 > 2048 ? 2048 : (n_out + 255) / 256);
+    hipLaunchKernelGGL(resample_poly_kernel, dim3(gx, B), dim3(256), 0, s, x, Lin, h, ntaps, up, down, n_pre_remove, y, n_out);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
+// x[b, :] /= max |x[b, :]|   (speech / np.max(np.abs(speech)), example.py:17); one workgroup per utterance
+__global__ __launch_bounds__(1024) void peak_normalize_kernel(float *__restrict__ x, long long L) {
+    __shared__ float red[1024];
+    float *row = x + (long long)blockIdx.x * L;
+    float mx = 0.0f;
+    for (long long i = threadIdx.x; i < L; i += blockDim.x) mx = fmaxf(mx, fabsf(row[i]));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    const float peak = red[0];
+    if (peak > 0.0f)
+        for (long long i = threadIdx.x; i < L; i += blockDim.x) row[i] = row[i] / peak;
+}
+
+int launch_peak_normalize(float *x, int B, long long L, hipStream_t s) {
+    if (B <= 0 || L <= 0) return BVC_OK;
+    hipLaunchKernelGGL(peak_normalize_kernel, dim3(B), dim3(1024), 0, s, x, L);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
 int launch_stft_logmel(const FrontendTables &t, const float *wav, int B, long long L, long long T,
                        int pad_left, float scale, float *mel, hipStream_t s) {
     const long long nframes = (long long)B * T;

@@ -125,6 +125,14 @@ int bvc_encode(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, flo
 int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, int64_t length,
                float out_scale_div, float *d_wav, void *d_ws, size_t ws_bytes, void *stream);
 
+/* Pre-processing of the reference's example.py:15-17.
+ * bvc_resample_poly: y = upfirdn(h, x, up, down)[n_pre_remove : n_pre_remove + n_out] with zero padding, i.e.
+ * scipy.signal.resample_poly once the caller has designed / padded the filter h (float64, device memory) as
+ * scipy does; d_x (B, L_in) -> d_y (B, n_out).  bvc_peak_normalize: x[b,:] /= max|x[b,:]| in place. */
+int bvc_resample_poly(const float *d_x, int32_t B, int64_t L_in, const double *d_h, int32_t ntaps, int32_t up,
+                      int32_t down, int64_t n_pre_remove, float *d_y, int64_t n_out, void *stream);
+int bvc_peak_normalize(float *d_x, int32_t B, int64_t L, void *stream);
+
 /* Wire format for the codes (new: the reference keeps them as float32 {0,1,0.5}, bvrnn.py:191-196, and
  * defines no bit stream).  A frame is ceil(nbits/8) bytes, bit i at byte i/8 position i%8 (LSB first);
  * nbits = min(z_dim, bits per frame) active bits are kept, the masked ones (0.5) are re-created on

@@ -116,3 +116,32 @@ def test_config_validation(tmp_path):
         config.load_config(str(p))
     c64 = config.load_config(config.DEFAULT_CONFIG_64BIT)
     assert c64["var_bit"] is False
+
+
+def test_resampler_filter_design_matches_scipy():
+    """The restated Kaiser low-pass / padding of scipy.signal.resample_poly (example.py:15)."""
+    import scipy.signal as ss
+    from bvcodec import preprocess
+    h = preprocess.kaiser_lowpass(3201, 1.0 / 160)
+    assert np.abs(h - ss.firwin(3201, 1.0 / 160, window=("kaiser", 5.0))).max() < 1e-15
+    up, down, hp, npre = preprocess.design(22050, 24000)
+    assert (up, down) == (147, 160) and npre == 11 and len(hp) == 3201 + 160
+    # numpy emulation of the GPU kernel's index walk == scipy on a small signal
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(700)
+    ref = ss.resample_poly(x, 22050, 24000)
+    n_out = len(ref)
+    y = np.zeros(n_out)
+    for m in range(n_out):
+        pos = (m + npre) * down
+        i, k = pos // up, pos % up
+        if i >= len(x):
+            k += (i - (len(x) - 1)) * up
+            i = len(x) - 1
+        acc = 0.0
+        while k < len(hp) and i >= 0:
+            acc += hp[k] * x[i]
+            k += up
+            i -= 1
+        y[m] = acc
+    assert np.abs(y - ref).max() < 1e-12

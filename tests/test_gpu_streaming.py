@@ -78,3 +78,20 @@ def test_wire_format_roundtrip(model, bitrate, nbytes):
     assert np.array_equal(packed.cpu().numpy(), ref)
     # payload rate: 86.13 frames/s * nbytes * 8 bit
     assert abs(nbytes * 8 * 22050 / 256 - bitrate) < 8 * 86.2 or bitrate > 5512
+
+
+@pytest.mark.parametrize("fs_in,L", [(24000, 24000 + 17), (16000, 9000), (48000, 20001), (22050, 5000)])
+def test_preprocessing_matches_scipy(fs_in, L):
+    """example.py:15-17 on the GPU: resample_poly to 22.05 kHz + peak normalisation, vs scipy (float64)."""
+    import scipy.signal as ss
+    from bvcodec import preprocess
+    rng = np.random.default_rng(fs_in)
+    x = (0.3 * rng.standard_normal((3, L))).astype(np.float32)
+    x[1] = np.sin(2 * np.pi * 440.0 * np.arange(L) / fs_in).astype(np.float32)
+    ref = ss.resample_poly(x.astype(np.float64), 22050, fs_in, axis=1)
+    got = preprocess.resample_poly(torch.from_numpy(x).to(DEV), 22050, fs_in).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-6
+    refn = ref / np.max(np.abs(ref), axis=1, keepdims=True)
+    gotn = preprocess.prepare_speech(torch.from_numpy(x).to(DEV), fs_in).cpu().numpy()
+    assert np.abs(gotn - refn).max() < 2e-6 and abs(np.abs(gotn).max() - 1.0) < 1e-6
