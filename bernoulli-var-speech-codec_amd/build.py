@@ -30,7 +30,9 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            extra = (["-mllvm", "-amdgpu-kernarg-preload-count=16"]
+                     if (src == "k_gemm.hip" and os.environ.get("BVC_KERNARG_PRELOAD", "0") == "1") else [])
+            cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

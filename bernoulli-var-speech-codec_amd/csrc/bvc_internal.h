@@ -53,24 +53,28 @@ struct CallDesc {
 //       packed [M][dim] matrix per frame.
 struct DynPtr {
     float *base;
-    long long ld;
-    long long poff;
-    int kind, sel, dim, toff;
-    int packed;
+    int ld;                       // row stride in floats (static / parity kinds)
+    int poff;                     // parity kind: offset added when ((t + toff) & 1)
+    int meta;                     // kind | packed << 4 | sel << 8 | (toff + 8) << 16
+    int dim;                      // frame kind: floats per frame row
 };
-inline DynPtr dp_static(const float *p, long long ld, int packed = 0) { return DynPtr{const_cast<float *>(p), ld, 0, 0, 0, 0, 0, packed}; }
-inline DynPtr dp_frame(int sel, int dim, int toff = 0, int packed = 0) { return DynPtr{nullptr, 0, 0, 1, sel, dim, toff, packed}; }
-inline DynPtr dp_parity(float *p, long long ld, long long poff, int flip, int packed = 0) { return DynPtr{p, ld, poff, 2, 0, 0, flip, packed}; }
-inline DynPtr dp_null() { return DynPtr{nullptr, 0, 0, 0, 0, 0, 0, 0}; }
+inline int dp_meta(int kind, int packed, int sel, int toff) { return kind | (packed << 4) | (sel << 8) | ((toff + 8) << 16); }
+inline DynPtr dp_static(const float *p, long long ld, int packed = 0) { return DynPtr{const_cast<float *>(p), (int)ld, 0, dp_meta(0, packed, 0, 0), 0}; }
+inline DynPtr dp_frame(int sel, int dim, int toff = 0, int packed = 0) { return DynPtr{nullptr, 0, 0, dp_meta(1, packed, sel, toff), dim}; }
+inline DynPtr dp_parity(float *p, long long ld, long long poff, int flip, int packed = 0) { return DynPtr{p, (int)ld, (int)poff, dp_meta(2, packed, 0, flip), 0}; }
+inline DynPtr dp_null() { return DynPtr{nullptr, 0, 0, 0, 0}; }
+inline int dp_kind(const DynPtr &d) { return d.meta & 15; }
+inline int dp_packed(const DynPtr &d) { return (d.meta >> 4) & 1; }
 
 // One K-segment of a (possibly concatenated) input:  acc[grp] += x[M,K] @ w[rows,K]^T
 struct GemmSeg {
-    DynPtr       x;      // [M][ld]
     const float *w;      // weights in MFMA B-operand fragment order [n/16][k/16][lane][4], already offset
                          // to this segment's first k-block
     int          wnb;    // k-blocks (of 16) per weight row, i.e. floats between n-tiles / 256
     int          K;      // multiple of 16
+    DynPtr       x;      // [M][ld]
     int          grp;    // accumulator group (0: input part, 1: hidden part of the GRU)
+    int          pad_;
 };
 
 enum GemmEpi {
@@ -83,18 +87,23 @@ enum GemmEpi {
                          //   gi = acc + y2part (W_ih[:, H:] phi_z + b_ih), gh = y3part (W_hh h + b_hh)
 };
 
+// The first 16 dwords (M .. seg[0].x) hold everything a layer needs to map its tile and issue the operand
+// loads of its first segment, so they can be pre-loaded into SGPRs at dispatch (build with
+// BVC_KERNARG_PRELOAD=1 -> -mllvm -amdgpu-kernarg-preload-count=16; worth 0.3 us per layer in
+// tools/skinny_bench, neutral in the full schedule, hence off by default).
 struct GemmParams {
+    int     M, N;              // N = outputs per gate (multiple of 16)
+    int     nb_total;          // sum over segments of K/16
+    int     gate_rows;         // row distance between gates inside w (GRU: h_dim); bias index stride
     GemmSeg seg[3];
     int     nseg;
-    int     M, N;              // N = outputs per gate (multiple of 16)
-    long long gate_rows;       // row distance between gates inside w (GRU: h_dim); bias index stride
-    const float *bias0;        // group 0 bias [gates*N]
+    int     var_bit;
+    const float *bias0;        // group 0 bias [gates*N] (may be null)
     const float *bias1;        // group 1 bias (GRU only)
     DynPtr  y, y2, y3;         // outputs (y2/y3 optional)
     DynPtr  aux;               // CODE: bits per frame (one per row); GRU: previous h; ELU: optional addend
     const float *part_i; const float *part_h; long long ldpart;   // GRU_PART: side-branch partial sums [M][3H]
     const float *mean; const float *stdv; // MEL epilogue
-    int     var_bit;
     const CallDesc *desc;      // null for stand-alone launches (all pointers static)
     unsigned long long *probe; // in-kernel timing slots, set only in the probe variant of a step graph
     int     node;              // index of this kernel inside its step (probe slot)

@@ -443,14 +443,20 @@ int check_ws(const bvc_model *m, int B, int64_t T, void *d_ws, size_t ws_bytes, 
     return BVC_OK;
 }
 
+inline GemmSeg mkseg(DynPtr x, const float *w, int wnb, int K, int grp) { return GemmSeg{w, wnb, K, x, grp, 0}; }
+
+// keeps nb_total consistent with the segments
+inline void finish(GemmParams &p) { p.nb_total = 0; for (int i = 0; i < p.nseg; ++i) p.nb_total += p.seg[i].K / 16; }
+
 GemmParams lin_params(const Linear &l, DynPtr x, int M, DynPtr y) {
     GemmParams p;
     memset(&p, 0, sizeof(p));
     p.nseg = 1;
-    p.seg[0] = GemmSeg{x, l.wp, l.in / 16, l.in, 0};
+    p.seg[0] = mkseg(x, l.wp, l.in / 16, l.in, 0);
     p.M = M; p.N = l.out; p.gate_rows = 0;
     p.bias0 = l.b;
     p.y = y;
+    finish(p);
     return p;
 }
 
@@ -458,8 +464,9 @@ GemmParams lin_params(const Linear &l, DynPtr x, int M, DynPtr y) {
 GemmParams lin2_params(const Linear &l, DynPtr x1, int K1, DynPtr x2, int K2, int M, DynPtr y) {
     GemmParams p = lin_params(l, x1, M, y);
     p.nseg = 2;
-    p.seg[0] = GemmSeg{x1, l.wp, l.in / 16, K1, 0};
-    p.seg[1] = GemmSeg{x2, l.wp + (size_t)(K1 / 16) * 256, l.in / 16, K2, 0};
+    p.seg[0] = mkseg(x1, l.wp, l.in / 16, K1, 0);
+    p.seg[1] = mkseg(x2, l.wp + (size_t)(K1 / 16) * 256, l.in / 16, K2, 0);
+    finish(p);
     return p;
 }
 
@@ -496,6 +503,7 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
     auto K = [&](int branch, GemmParams p, int epi) {
         p.desc = w.desc; p.node = node++;
         p.probe = g_kprobe.enabled ? g_kprobe.dev : nullptr;
+        finish(p);
         plan.push_back(StepNode{OP_KERNEL, branch, -1, p, epi});
     };
     auto REC = [&](int branch, int ev) { GemmParams z; memset(&z, 0, sizeof(z)); if (side) plan.push_back(StepNode{OP_RECORD, branch, ev, z, 0}); };
@@ -503,7 +511,7 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
     // --- side-branch kernels (plain linears into natural [B][.] partial buffers)
     auto side_dec0h = [&]() {       // dec.0.weight[:, H:] @ h            (no bias: added on the main branch)
         GemmParams p = lin_params(m->dec[0], h_cur, B, dp_static(w.part_d, H));
-        p.seg[0] = GemmSeg{h_cur, m->dec[0].wp + (size_t)(H / 16) * 256, 2 * H / 16, H, 0};
+        p.seg[0] = mkseg(h_cur, m->dec[0].wp + (size_t)(H / 16) * 256, 2 * H / 16, H, 0);
         p.bias0 = nullptr;
         K(BR_SIDE, p, EPI_LINEAR);
     };
@@ -511,7 +519,7 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
         GemmParams p;
         memset(&p, 0, sizeof(p));
         p.nseg = 1;
-        p.seg[0] = GemmSeg{h_cur, m->w_hh, H / 16, H, 0};
+        p.seg[0] = mkseg(h_cur, m->w_hh, H / 16, H, 0);
         p.M = B; p.N = 3 * H; p.bias0 = m->b_hh;
         p.y = dp_static(w.part_h, 3 * H);
         K(BR_SIDE, p, EPI_LINEAR);
@@ -520,7 +528,7 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
         GemmParams p;
         memset(&p, 0, sizeof(p));
         p.nseg = 1;
-        p.seg[0] = GemmSeg{pz, m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0};
+        p.seg[0] = mkseg(pz, m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0);
         p.M = B; p.N = 3 * H; p.bias0 = m->b_ih;
         p.y = dp_static(w.part_i, 3 * H);
         K(BR_SIDE, p, EPI_LINEAR);
@@ -545,7 +553,7 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
     const int n_dec0 = node;
     if (side) {      // dec.0 on the critical path only sees phi_z; the h half arrives from the side branch
         GemmParams p = lin_params(m->dec[0], pz_final, B, S(d1, H));
-        p.seg[0] = GemmSeg{pz_final, m->dec[0].wp, 2 * H / 16, H, 0};
+        p.seg[0] = mkseg(pz_final, m->dec[0].wp, 2 * H / 16, H, 0);
         p.aux = dp_static(w.part_d, H);
         WAIT(BR_MAIN, EV_DEC0H);
         K(BR_MAIN, p, EPI_ELU);
@@ -572,15 +580,15 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
         p.aux = h_cur;
         if (side) {
             p.nseg = 1;
-            p.seg[0] = GemmSeg{S(g3, H), m->w_ih, 2 * H / 16, H, 0};                    // W_ih[:, :H] @ phi_x_gen
+            p.seg[0] = mkseg(S(g3, H), m->w_ih, 2 * H / 16, H, 0);                    // W_ih[:, :H] @ phi_x_gen
             p.part_i = w.part_i; p.part_h = w.part_h; p.ldpart = 3LL * H;
             WAIT(BR_MAIN, EV_GATES);
             K(BR_MAIN, p, EPI_GRU_PART);
         } else {
             p.nseg = 3;
-            p.seg[0] = GemmSeg{S(g3, H), m->w_ih, 2 * H / 16, H, 0};                    // cat([phi_x_gen, phi_z]) bvrnn.py:206
-            p.seg[1] = GemmSeg{pz_final, m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0};
-            p.seg[2] = GemmSeg{h_cur, m->w_hh, H / 16, H, 1};
+            p.seg[0] = mkseg(S(g3, H), m->w_ih, 2 * H / 16, H, 0);                    // cat([phi_x_gen, phi_z]) bvrnn.py:206
+            p.seg[1] = mkseg(pz_final, m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0);
+            p.seg[2] = mkseg(h_cur, m->w_hh, H / 16, H, 1);
             p.bias0 = m->b_ih; p.bias1 = m->b_hh;
             K(BR_MAIN, p, EPI_GRU);
         }

@@ -51,14 +51,16 @@ __device__ __forceinline__ long long sload_i64(const void *p) {
 // The frame counter is read from the descriptor only by pointers that need it (kind 1/2): layers whose
 // operands are all workspace-static never wait for that line.
 __device__ __forceinline__ Resolved resolve(const DynPtr &d, const CallDesc *c, int mt16, int tstep) {
-    if (d.kind == 0) return {d.base, d.ld, d.base != nullptr, d.packed};
+    const int kind = d.meta & 15, packed = (d.meta >> 4) & 1;
+    if (kind == 0) return {d.base, (long long)d.ld, d.base != nullptr, packed};
+    const int toff = ((d.meta >> 16) & 255) - 8;
     const int t = sload_i32(&c->t) + tstep;
-    if (d.kind == 2) return {d.base + (((t + d.toff) & 1) ? d.poff : 0), d.ld, true, d.packed};
+    if (kind == 2) return {d.base + (((t + toff) & 1) ? d.poff : 0), (long long)d.ld, true, packed};
     const long long T = sload_i64(&c->T);
-    float *b = reinterpret_cast<float *>(sload_i64(&c->p[d.sel]));
-    const long long tt = (long long)t + d.toff;
+    float *b = reinterpret_cast<float *>(sload_i64(&c->p[(d.meta >> 8) & 255]));
+    const long long tt = (long long)t + toff;
     const bool ok = (b != nullptr) && tt >= 0 && tt < T;
-    if (d.packed) return {ok ? b + tt * (long long)mt16 * d.dim : nullptr, (long long)d.dim, ok, 1};
+    if (packed) return {ok ? b + tt * (long long)mt16 * d.dim : nullptr, (long long)d.dim, ok, 1};
     return {ok ? b + tt * d.dim : nullptr, T * d.dim, ok, 0};
 }
 
@@ -163,9 +165,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
 #pragma unroll
     for (int q = 0; q < NG; ++q) acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int nb = 0;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) nb += (s < p.nseg) ? (p.seg[s].K >> 4) : 0;
+    const int nb = p.nb_total;
     const int my_lo = (int)(((long long)nb * wave) / NW);
     const int my_hi = (int)(((long long)nb * (wave + 1)) / NW);
     const int xrow = (m0 + r) < p.M ? (m0 + r) : (p.M - 1);      // natural layout: clamp (row never stored)
@@ -173,13 +173,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     int base = 0;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        if (s >= p.nseg) break;
+        if (s > 0 && s >= p.nseg) break;
         const int sb = p.seg[s].K >> 4;
         int lo = my_lo - base, hi = my_hi - base;
         lo = lo < 0 ? 0 : lo;
         hi = hi > sb ? sb : hi;
         if (lo < hi) {
-            const long long gate_stride = (long long)(p.gate_rows >> 4) * p.seg[s].wnb * 256;
+            const long long gate_stride = (long long)(p.gate_rows >> 4) * p.seg[s].wnb * 256;      // floats between gates
             const float *wl = p.seg[s].w + (long long)ntile * p.seg[s].wnb * 256 + lane * 4;
             if constexpr (NGRP == 1) {
                 run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
@@ -297,14 +297,15 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s) {
     int nb = 0;
     for (int i = 0; i < p.nseg; ++i) {
         const DynPtr &x = p.seg[i].x;
-        const long long xl = x.kind == 1 ? x.dim : x.ld;
-        if (p.seg[i].K % 16 || xl % (x.packed ? 16 : 4) || p.seg[i].wnb <= 0) {
+        const long long xl = dp_kind(x) == 1 ? x.dim : x.ld;
+        if (p.seg[i].K % 16 || xl % (dp_packed(x) ? 16 : 4) || p.seg[i].wnb <= 0) {
             set_error("gemm_skinny: segment %d K=%d row length %lld: K must be a multiple of 16, rows of 4 (16 packed)",
                       i, p.seg[i].K, xl);
             return BVC_EINVAL;
         }
         nb += p.seg[i].K / 16;
     }
+    if (nb != p.nb_total) { set_error("gemm_skinny: nb_total %d does not match the segments (%d)", p.nb_total, nb); return BVC_EINVAL; }
     const int n_tiles = p.N / 16, m_tiles = (p.M + 15) / 16;
     const int grid = 8 * ((n_tiles + 7) / 8) * m_tiles;
     ProbeScope probe((epi == EPI_GRU || epi == EPI_GRU_PART) ? PK_GRU : PK_LINEAR, s);
