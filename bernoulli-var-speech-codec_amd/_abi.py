@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (loads torch's libamdhip64 first so the library binds to the same HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbvcodec_hip.so")
+LIB_PATH = os.environ.get("BVC_LIB") or os.path.join(_HERE, "csrc", "libbvcodec_hip.so")   # BVC_LIB: experiments only
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 

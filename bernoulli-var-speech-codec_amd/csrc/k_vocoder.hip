@@ -175,7 +175,7 @@ struct AmpArgs {
 };
 
 template <int C, int MT>
-__global__ __launch_bounds__(256) void amp_pair_kernel(AmpArgs a) {
+__global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int S = C + 2;
     constexpr int NT = (C + 15) / 16;
@@ -292,8 +292,26 @@ __global__ __launch_bounds__(256) void amp_pair_kernel(AmpArgs a) {
     __syncthreads();
 
     // ---- phase 3: x' = conv2(t2) + b2 + x   (+ running sum over the AMP blocks, / num_kernels)
-    mma(t2, 1, a.w2);
+    // The residual (and running-sum) operands are fetched BEFORE the MFMA loop so that their latency is
+    // covered by it instead of being exposed in the epilogue.
     const long long ob = (long long)b * a.L;
+    float resv[MT][NT][4], accv[MT][NT][4];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = n * 16 + r;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = mbase + i * 16 + g * 4 + e;
+                const long long t = t0 + row;
+                const bool ok = col < C && row < TT && t < a.L;
+                const long long o = (ob + (ok ? t : 0)) * C + (ok ? col : 0);
+                resv[i][n][e] = ok ? a.x[o] : 0.0f;
+                accv[i][n][e] = (ok && a.epi >= CE_RES_ACC) ? a.acc[o] : 0.0f;
+            }
+    }
+    mma(t2, 1, a.w2);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int col = n * 16 + r;
@@ -308,8 +326,8 @@ __global__ __launch_bounds__(256) void amp_pair_kernel(AmpArgs a) {
                 if (row >= TT || t >= a.L) continue;
                 const long long o = (ob + t) * C + col;
                 float v = acc[i][n][e] + bias;
-                v = v + a.x[o];                                      // x = xt + x      (models.py:119)
-                if (a.epi >= CE_RES_ACC) v = a.acc[o] + v;           // xs += resblock  (models.py:224)
+                v = v + resv[i][n][e];                               // x = xt + x      (models.py:119)
+                if (a.epi >= CE_RES_ACC) v = accv[i][n][e] + v;      // xs += resblock  (models.py:224)
                 if (a.epi == CE_RES_ACC_DIV) v = v / a.divisor;      // xs / num_kernels (models.py:225)
                 a.out[o] = v;
             }
