@@ -16,8 +16,8 @@ algorithm for the path (citations are relative to the reference checkout):
                      ``third_party/BigVGAN/requirements.txt:3``) and not installed in the
                      image: its published algorithm is restated; parity at this one
                      boundary is pinned against the independent implementation
-                     ``transformers.audio_utils.mel_filter_bank`` (see
-                     ``tests/test_oracle_golden.py``), i.e. "parity unpinned" w.r.t.
+                     ``transformers.audio_utils.mel_filter_bank`` (captured by
+                     ``tests/golden/make_melbank_pin.py``, checked in ``tests/test_oracle_golden.py``), i.e. "parity unpinned" w.r.t.
                      librosa itself.
 * ``frontend.py``  - ``mel_spectrogram``  (``meldataset.py:60-95``, ``:38-39``).
 * ``bvrnn.py``     - ``BVRNN.encode`` / ``BVRNN.decode`` (``bvrnn.py:163-229``, nets
