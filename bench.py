@@ -136,9 +136,12 @@ def main():
     gathered = ([torch.empty(world * B, L, device=device) for _ in range(nstreams)]
                 if (use_pg and not a.no_gather) else None)
 
-    def step(slot=0):
+    def local_step():
         codes = model.encode(x, BITRATE)
-        wav = model.decode(codes, L)
+        return codes, model.decode(codes, L)
+
+    def step(slot=0):
+        codes, wav = local_step()
         if gathered is not None:                  # the "final gather" of the north star: one RCCL collective
             torch.distributed.all_gather_into_tensor(gathered[slot], wav)
         return codes, wav
@@ -220,7 +223,7 @@ def main():
                           "timer": "in-kernel wall_clock64 (first workgroup start -> last workgroup end)"}
         for kind in (3, 4, 5, 6):               # eagerly launched kernels: hipEvent pairs around every launch
             _abi.check(lib.bvc_probe_begin(kind, 1, 4096))
-            step()
+            local_step()                        # rank 0 only: no collective here
             mean, mn, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
             _abi.check(lib.bvc_probe_end(ctypes.byref(mean), ctypes.byref(mn), ctypes.byref(n)))
             fl, launches = fam[kind]
