@@ -665,10 +665,15 @@ int get_step_graph(const bvc_model *m, const Workspace &w, void *ws_base, int B,
         hipError_t e = hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal);
         int rc = BVC_OK;
         if (e == hipSuccess) rc = launch_steps(m, plan, w, which ? GRAPH_STEPS : 1, m->cap_stream, m->side_branch ? m->side_stream : nullptr);
+        // always close the capture, also when a launch inside it failed, so the stream stays usable
         hipError_t e2 = (e == hipSuccess) ? hipStreamEndCapture(m->cap_stream, &graph) : e;
         g_capturing = false;
-        if (rc) return rc;
-        if (e2 != hipSuccess || !graph) { set_error("hipGraph capture failed: %s", hipGetErrorString(e2)); return BVC_EHIP; }
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); if (sg.exec1) (void)hipGraphExecDestroy(sg.exec1); return rc; }
+        if (e2 != hipSuccess || !graph) {
+            if (sg.exec1) (void)hipGraphExecDestroy(sg.exec1);
+            set_error("hipGraph capture failed: %s", hipGetErrorString(e2));
+            return BVC_EHIP;
+        }
         hipGraphExec_t ex = nullptr;
         BVC_HIP_TRY(hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0));
         BVC_HIP_TRY(hipGraphDestroy(graph));
