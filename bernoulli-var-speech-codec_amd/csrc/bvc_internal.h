@@ -110,7 +110,7 @@ struct GemmParams {
     int     tstep;             // static frame offset inside an unrolled multi-step graph: t = desc->t + tstep
 };
 
-int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s);
+int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s, int mtw = 1);
 int skinny_kernels_init();
 int launch_step_advance(CallDesc *d, int by, hipStream_t s);
 int launch_set_desc(CallDesc *d, const CallDesc &v, hipStream_t s);

@@ -82,6 +82,7 @@ struct bvc_model {
     bool side_branch = false;   // measured SLOWER on MI355X (cross-branch graph dependencies + no spare L2->CU bandwidth): opt-in
     bool use_graph = true;
     bool fused_amp = true;
+    int mtw = 1;                // 16-row tiles per workgroup in the recurrent kernels (BVC_MTW = 1 | 2 | 4)
 
     ~bvc_model() {
         for (auto &g : graphs) { (void)hipGraphExecDestroy(g.exec1); (void)hipGraphExecDestroy(g.execN); }
@@ -634,7 +635,7 @@ int launch_steps(const bvc_model *m, const std::vector<StepNode> &plan, const Wo
             if (n.op == OP_KERNEL) {
                 GemmParams p = n.p;
                 p.tstep = k;
-                if ((rc = launch_gemm_skinny(p, n.epi, st))) return rc;
+                if ((rc = launch_gemm_skinny(p, n.epi, st, m->mtw))) return rc;
             } else if (side) {
                 if (n.op == OP_RECORD) BVC_HIP_TRY(hipEventRecord(m->cap_events[n.event], st));
                 else                   BVC_HIP_TRY(hipStreamWaitEvent(st, m->cap_events[n.event], 0));
@@ -867,6 +868,8 @@ int bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t n
         m->use_graph = !(ng && ng[0] == '1');
         const char *sb = getenv("BVC_SIDE_BRANCH");
         m->side_branch = (sb && sb[0] == '1');
+        const char *mw = getenv("BVC_MTW");
+        if (mw && (mw[0] == '2' || mw[0] == '4')) m->mtw = mw[0] - '0';
         const char *ua = getenv("BVC_UNFUSED_AMP");
         m->fused_amp = !(ua && ua[0] == '1');
     }

@@ -16,6 +16,8 @@
 //
 // Reference semantics: nn.Linear / nn.ELU / nn.Sigmoid / torch.round / nn.GRU as used at
 // bvrnn.py:44-83,163-229.
+#include <cstdlib>
+
 #include "bvc_internal.h"
 
 namespace bvc {
@@ -74,27 +76,32 @@ __device__ __forceinline__ void store_out(const Resolved &y, int m, int n, float
     else y.p[(long long)m * y.ld + n] = v;
 }
 
-// Accumulate k-blocks [lo, hi) of one segment into acc[NG].  wl: this lane's pointer into the packed
+// Accumulate k-blocks [lo, hi) of one segment into acc[MTW][NG].  wl: this lane's pointer into the packed
 // weights of (n-tile, gate 0, k-block 0).  The weight loads of the first chunk are issued BEFORE the
 // activation pointer is resolved: weight addresses come from kernel arguments only, while a frame- or
 // parity-indexed activation pointer needs the frame counter from the call descriptor (a dependent
 // load of a line another kernel has just written), whose latency is thus hidden behind the weights.
-template <int NG, int U>
+// MTW row tiles share every weight fragment in registers (weights cross the L2->CU path once per MTW*16 rows).
+template <int NG, int U, int MTW>
 __device__ __forceinline__ void run_segment(const float *wl, long long gate_stride, const DynPtr &xd,
-                                            const CallDesc *dsc, int mt16, int tstep, int mtile, int xrow, int lane,
-                                            int g, int lo, int hi, f32x4 (&acc)[NG]) {
-    const float *xl = nullptr;
+                                            const CallDesc *dsc, int mt16, int tstep, const int (&mtile)[MTW],
+                                            const int (&xrow)[MTW], int lane, int g, int lo, int hi,
+                                            f32x4 (&acc)[MTW][NG]) {
+    const float *xl[MTW];
     int xstep = 0;
     bool have_x = false;
     auto resolve_x = [&]() {
         const Resolved x = resolve(xd, dsc, mt16, tstep);
-        if (x.packed) { xl = x.p + (long long)mtile * (x.ld >> 4) * 256 + lane * 4; xstep = 256; }
-        else          { xl = x.p + (long long)xrow * x.ld + g * 4;                  xstep = 16; }
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+            if (x.packed) { xl[j] = x.p + (long long)mtile[j] * (x.ld >> 4) * 256 + lane * 4; xstep = 256; }
+            else          { xl[j] = x.p + (long long)xrow[j] * x.ld + g * 4;                  xstep = 16; }
+        }
         have_x = true;
     };
     int kb = lo;
     for (; kb + U <= hi; kb += U) {
-        f32x4 xv[U];
+        f32x4 xv[U][MTW];
         f32x4 wv[U][NG];
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -103,14 +110,18 @@ __device__ __forceinline__ void run_segment(const float *wl, long long gate_stri
                 wv[u][q] = *reinterpret_cast<const f32x4 *>(wl + (long long)q * gate_stride + (long long)(kb + u) * 256);
         if (!have_x) resolve_x();
 #pragma unroll
-        for (int u = 0; u < U; ++u) xv[u] = *reinterpret_cast<const f32x4 *>(xl + (long long)(kb + u) * xstep);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < MTW; ++j) xv[u][j] = *reinterpret_cast<const f32x4 *>(xl[j] + (long long)(kb + u) * xstep);
         __builtin_amdgcn_sched_barrier(0);      // keep all U blocks' loads in flight ahead of the MFMAs
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int q = 0; q < NG; ++q) acc[q] = mfma16(xv[u][e], wv[u][q][e], acc[q]);
+                for (int j = 0; j < MTW; ++j)
+#pragma unroll
+                    for (int q = 0; q < NG; ++q) acc[j][q] = mfma16(xv[u][j][e], wv[u][q][e], acc[j][q]);
         }
     }
     for (; kb < hi; ++kb) {
@@ -119,17 +130,20 @@ __device__ __forceinline__ void run_segment(const float *wl, long long gate_stri
         for (int q = 0; q < NG; ++q)
             wv[q] = *reinterpret_cast<const f32x4 *>(wl + (long long)q * gate_stride + (long long)kb * 256);
         if (!have_x) resolve_x();
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xl + (long long)kb * xstep);
 #pragma unroll
-        for (int q = 0; q < NG; ++q)
+        for (int j = 0; j < MTW; ++j) {
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(xl[j] + (long long)kb * xstep);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[q] = mfma16(xv[e], wv[q][e], acc[q]);
+            for (int q = 0; q < NG; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][q] = mfma16(xv[e], wv[q][e], acc[j][q]);
+        }
     }
 }
 
-template <int NG, int NGRP, int NW, int U>
+template <int NG, int NGRP, int NW, int U, int MTW>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int epi) {
-    extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][NGRP*NG][256]
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][NGRP*NG][MTW][256]
     const int tid = threadIdx.x, lane = tid & 63;
     const CallDesc *dsc = p.desc;
     unsigned long long t_start = 0;
@@ -137,13 +151,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
 
     const int n_tiles = p.N >> 4;
     const int m_tiles = (p.M + 15) >> 4;
+    const int m_groups = (m_tiles + MTW - 1) / MTW;                  // MTW row tiles per workgroup
     const int mt16 = m_tiles << 4;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
-    const int ntile = (slot / m_tiles) * 8 + xcd;
-    const int mtile = slot % m_tiles;
+    const int ntile = (slot / m_groups) * 8 + xcd;
+    const int mgroup = slot % m_groups;
     if (ntile >= n_tiles) return;                                    // uniform per workgroup
-    const int m0 = mtile << 4, n0 = ntile << 4;
+    const int n0 = ntile << 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
 
@@ -159,16 +174,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
         }
     }
 
-    f32x4 acc0[NG], acc1[NG];
+    int mtile[MTW], xrow[MTW];
 #pragma unroll
-    for (int q = 0; q < NG; ++q) acc0[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MTW; ++j) {
+        const int mt = mgroup * MTW + j;
+        mtile[j] = mt < m_tiles ? mt : m_tiles - 1;                  // a missing tile re-reads the last one; never stored
+        const int row = (mtile[j] << 4) + r;
+        xrow[j] = row < p.M ? row : p.M - 1;                         // natural layout: clamp (row never stored)
+    }
+
+    f32x4 acc0[MTW][NG], acc1[MTW][NG];
 #pragma unroll
-    for (int q = 0; q < NG; ++q) acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+        for (int q = 0; q < NG; ++q) { acc0[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     const int nb = p.nb_total;
     const int my_lo = (int)(((long long)nb * wave) / NW);
     const int my_hi = (int)(((long long)nb * (wave + 1)) / NW);
-    const int xrow = (m0 + r) < p.M ? (m0 + r) : (p.M - 1);      // natural layout: clamp (row never stored)
 
     int base = 0;
 #pragma unroll
@@ -182,12 +205,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             const long long gate_stride = (long long)(p.gate_rows >> 4) * p.seg[s].wnb * 256;      // floats between gates
             const float *wl = p.seg[s].w + (long long)ntile * p.seg[s].wnb * 256 + lane * 4;
             if constexpr (NGRP == 1) {
-                run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
+                run_segment<NG, U, MTW>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
             } else {
                 if (p.seg[s].grp == 0)
-                    run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
+                    run_segment<NG, U, MTW>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
                 else
-                    run_segment<NG, U>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc1);
+                    run_segment<NG, U, MTW>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc1);
             }
         }
         base += sb;
@@ -195,26 +218,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
 
     // ---- cross-wave reduction through LDS, fixed order (deterministic)
 #pragma unroll
-    for (int q = 0; q < NG; ++q)
+    for (int j = 0; j < MTW; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = ((g * 4 + e) << 4) + r;                  // D[row=g*4+e][col=r]
-            red[(wave * NACC + q) * 256 + idx] = acc0[q][e];
-            if (NGRP > 1) red[(wave * NACC + NG + q) * 256 + idx] = acc1[q][e];
-        }
+        for (int q = 0; q < NG; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = ((g * 4 + e) << 4) + r;              // D[row=g*4+e][col=r]
+                red[((wave * NACC + q) * MTW + j) * 256 + idx] = acc0[j][q][e];
+                if (NGRP > 1) red[((wave * NACC + NG + q) * MTW + j) * 256 + idx] = acc1[j][q][e];
+            }
     __syncthreads();
     if (tid >= 256) return;
-    float v[NACC];
+    const int i = tid >> 4, jj = tid & 15;
+    const int n = n0 + jj;
+#pragma unroll 1
+    for (int j = 0; j < MTW; ++j) {
+        const int mt = mgroup * MTW + j;
+        const int m = (mt << 4) + i;
+        if (mt >= m_tiles || m >= p.M) continue;
+        float v[NACC];
 #pragma unroll
-    for (int a = 0; a < NACC; ++a) {
-        float sum = red[a * 256 + tid];
+        for (int a = 0; a < NACC; ++a) {
+            float sum = red[(a * MTW + j) * 256 + tid];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) sum += red[(w * NACC + a) * 256 + tid];
-        v[a] = sum + bias[a];
-    }
-    const int i = tid >> 4, j = tid & 15;
-    const int m = m0 + i, n = n0 + j;
-    if (m < p.M) {
+            for (int w = 1; w < NW; ++w) sum += red[((w * NACC + a) * MTW + j) * 256 + tid];
+            v[a] = sum + bias[a];
+        }
         const Resolved y = resolve(p.y, dsc, mt16, p.tstep);
         if (epi == EPI_LINEAR || epi == EPI_ELU) {
             float o = v[0];
@@ -279,19 +308,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     }
 }
 
-template <int NG, int NGRP, int NW, int U>
-static void launch_skinny_t(const GemmParams &p, int epi, int grid, hipStream_t s) {
-    const size_t lds = (size_t)NW * NG * NGRP * 256 * sizeof(float);
-    hipLaunchKernelGGL((gemm_skinny_kernel<NG, NGRP, NW, U>), dim3(grid), dim3(NW * 64), lds, s, p, epi);
+template <int NG, int NGRP, int NW, int U, int MTW>
+static void launch_skinny_t(const GemmParams &p, int epi, hipStream_t s) {
+    const int n_tiles = p.N / 16, m_tiles = (p.M + 15) / 16, m_groups = (m_tiles + MTW - 1) / MTW;
+    const int grid = 8 * ((n_tiles + 7) / 8) * m_groups;
+    const size_t lds = (size_t)NW * NG * NGRP * MTW * 256 * sizeof(float);
+    hipLaunchKernelGGL((gemm_skinny_kernel<NG, NGRP, NW, U, MTW>), dim3(grid), dim3(NW * 64), lds, s, p, epi);
 }
 
-int skinny_kernels_init() {
-    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_skinny_kernel<3, 2, 16, 3>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 6 * 1024));
+template <typename K>
+static int allow_lds(K kern, int bytes) {
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     return BVC_OK;
 }
 
-int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s) {
+int skinny_kernels_init() {
+    int rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 16, 3, 1>, 16 * 6 * 1024))) return rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 8, 3, 2>, 8 * 6 * 2 * 1024))) return rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 4, 2, 4>, 4 * 6 * 4 * 1024))) return rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<1, 1, 16, 4, 4>, 16 * 4 * 1024))) return rc;
+    return BVC_OK;
+}
+
+// mtw = row tiles (of 16) per workgroup: 1 maximises the number of workgroups (lowest latency of a single
+// dependent chain), 2 / 4 share every weight fragment among more rows (less L2->CU traffic: higher
+// throughput when several independent chains run concurrently).
+int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s, int mtw) {
     if (p.M <= 0) return BVC_OK;
     if (p.N % 16) { set_error("gemm_skinny: N=%d not a multiple of 16", p.N); return BVC_EINVAL; }
     int nb = 0;
@@ -306,13 +349,27 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s) {
         nb += p.seg[i].K / 16;
     }
     if (nb != p.nb_total) { set_error("gemm_skinny: nb_total %d does not match the segments (%d)", p.nb_total, nb); return BVC_EINVAL; }
-    const int n_tiles = p.N / 16, m_tiles = (p.M + 15) / 16;
-    const int grid = 8 * ((n_tiles + 7) / 8) * m_tiles;
+    const int m_tiles = (p.M + 15) / 16;
+    if (mtw > m_tiles) mtw = m_tiles >= 4 ? 4 : (m_tiles >= 2 ? 2 : 1);
+    if (mtw != 2 && mtw != 4) mtw = 1;
     ProbeScope probe((epi == EPI_GRU || epi == EPI_GRU_PART) ? PK_GRU : PK_LINEAR, s);
-    if (epi == EPI_GRU)           launch_skinny_t<3, 2, 16, 3>(p, epi, grid, s);
-    else if (epi == EPI_GRU_PART) launch_skinny_t<3, 1, 8, 4>(p, epi, grid, s);
-    else if (nb >= 128)      launch_skinny_t<1, 1, 16, 8>(p, epi, grid, s);
-    else                     launch_skinny_t<1, 1, 8, 8>(p, epi, grid, s);
+    if (epi == EPI_GRU) {
+        if (mtw == 4)      launch_skinny_t<3, 2, 4, 2, 4>(p, epi, s);
+        else if (mtw == 2) launch_skinny_t<3, 2, 8, 3, 2>(p, epi, s);
+        else               launch_skinny_t<3, 2, 16, 3, 1>(p, epi, s);
+    } else if (epi == EPI_GRU_PART) {
+        launch_skinny_t<3, 1, 8, 4, 1>(p, epi, s);
+    } else if (nb >= 128) {          // K >= 2048: 16 waves
+        if (mtw == 4)      launch_skinny_t<1, 1, 16, 4, 4>(p, epi, s);
+        else if (mtw == 2) launch_skinny_t<1, 1, 16, 8, 2>(p, epi, s);
+        else               launch_skinny_t<1, 1, 16, 4, 1>(p, epi, s);
+    } else {
+        // mtw 1: chunks of 4 k-blocks (52 VGPRs) measured 2 % faster than chunks of 8 (88 VGPRs), alone and
+        // with three chains in flight
+        if (mtw == 4)      launch_skinny_t<1, 1, 8, 4, 4>(p, epi, s);
+        else if (mtw == 2) launch_skinny_t<1, 1, 8, 8, 2>(p, epi, s);
+        else               launch_skinny_t<1, 1, 8, 4, 1>(p, epi, s);
+    }
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }
