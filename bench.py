@@ -39,7 +39,7 @@ BATCH = 64
 SECONDS = 5.0
 BITRATE = 3000
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix = vector peak
-PROBE_NAMES = {1: "gemm_skinny_kernel<1,1,8|16,4,1> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<3,2,16,3,1> (GRU cell)",
+PROBE_NAMES = {1: "gemm_skinny_kernel<1,1,8|16,4,1> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<3,2,16,2,1> (GRU cell)",
                3: "amp_pair_kernel / conv_mfma_kernel (BigVGAN convs)", 4: "gemm_batched_kernel (phi_x / phi_z over all frames)",
                5: "stft_logmel_kernel", 6: "conv_post_kernel"}
 

@@ -324,7 +324,7 @@ static int allow_lds(K kern, int bytes) {
 
 int skinny_kernels_init() {
     int rc;
-    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 16, 3, 1>, 16 * 6 * 1024))) return rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 16, 2, 1>, 16 * 6 * 1024))) return rc;
     if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 8, 3, 2>, 8 * 6 * 2 * 1024))) return rc;
     if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 4, 2, 4>, 4 * 6 * 4 * 1024))) return rc;
     if ((rc = allow_lds(gemm_skinny_kernel<1, 1, 16, 4, 4>, 16 * 4 * 1024))) return rc;
@@ -356,7 +356,7 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s, int mtw) {
     if (epi == EPI_GRU) {
         if (mtw == 4)      launch_skinny_t<3, 2, 4, 2, 4>(p, epi, s);
         else if (mtw == 2) launch_skinny_t<3, 2, 8, 3, 2>(p, epi, s);
-        else               launch_skinny_t<3, 2, 16, 3, 1>(p, epi, s);
+        else               launch_skinny_t<3, 2, 16, 2, 1>(p, epi, s);
     } else if (epi == EPI_GRU_PART) {
         launch_skinny_t<3, 1, 8, 4, 1>(p, epi, s);
     } else if (nb >= 128) {          // K >= 2048: 16 waves
