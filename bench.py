@@ -193,6 +193,17 @@ def main():
                    "streams": len(streams)},
     }
 
+    if rank == 0 and len(streams) > 1:
+        # for reference: the same K steps issued back to back on ONE stream (latency-oriented number)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            local_step()
+        torch.cuda.synchronize(device)
+        dt1 = time.perf_counter() - t1
+        out["single_stream"] = {"value": round(B * a.seconds * a.steps / dt1, 2), "ms_per_step": round(1e3 * dt1 / a.steps, 3),
+                                "note": "one rank, one stream, no gather"}
+
     if rank == 0 and not a.no_roofline:
         lib = _abi.load()
         fam = flops_per_step(conf, B, T)
