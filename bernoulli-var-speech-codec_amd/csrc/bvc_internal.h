@@ -163,17 +163,21 @@ struct ConvLayer {               // one causal conv as implicit GEMM on fp32 MFM
     const float *act_ib;         // 1/(exp(beta)+1e-9)
 };
 enum ConvEpi { CE_STORE = 0, CE_RES = 1, CE_RES_ACC = 2, CE_RES_ACC_DIV = 3 };
+// Streaming window: the tensors are (B, rows, C) buffers whose first rows are history; only rows from
+// row_begin on are computed.  t_origin = global time of buffer row 0 (for the zero-before-start rule).
+struct ConvWindow { long long in_bs, out_bs, row_begin, t_origin; };
 // in (B, Lin, cin) channels-last; out (B, Lout, cout).  Output row r reads input rows
 // r - (ks-1)*dil ... r  (rows outside [0,Lin) are zero).  res/acc have the layout of out.
 int conv_kernels_init();
 int launch_conv_mfma(const ConvLayer &c, const float *in, long long Lin, float *out, long long Lout,
-                     int B, int epi, const float *res, const float *acc, float divisor, hipStream_t s);
+                     int B, int epi, const float *res, const float *acc, float divisor, hipStream_t s,
+                     const ConvWindow *win = nullptr);
 // one fused AMPBlock1 iteration: out = x + conv2(S2(conv1_dil(S1(x)))) (+acc, /divisor per epi); c2.dil == 1
 int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, long long L, float *out, int B, int epi,
-                    const float *acc, float divisor, hipStream_t s);
+                    const float *acc, float divisor, hipStream_t s, const ConvWindow *win = nullptr);
 // SnakeBeta -> causal conv C->1 (k taps) -> tanh -> / div -> first n_out samples
 int launch_conv_post(const float *in, long long Lin, int C, int ks, const float *w, const float *bias,
                      const float *act_a, const float *act_ib, float div, float *wav, long long n_out,
-                     int B, hipStream_t s);
+                     int B, hipStream_t s, const ConvWindow *win = nullptr);
 
 }  // namespace bvc

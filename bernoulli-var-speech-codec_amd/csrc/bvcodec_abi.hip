@@ -832,6 +832,118 @@ int run_vocoder(const bvc_model *m, const Workspace &w, const float *d_mel, int 
                             d_wav, n_out, B, s);
 }
 
+
+// ---- incremental (history-buffer) vocoder for streaming --------------------------------------------
+// Every activation tensor of the generator is kept as a (B, H + kmax*rate, C) buffer whose first H rows
+// are the last H rows of the previous hop; a hop computes only the rows of the new frames and then
+// rotates the last H rows to the front of the twin buffer (ping-pong: source and destination overlap
+// when fewer than H rows are new).
+struct StreamTensor { float *buf[2]; int C, H, rate; long long rows; };
+struct RotEntry { float *buf[2]; long long bs; int C, H, rate, pad_; };
+
+__global__ __launch_bounds__(256) void stream_rotate_kernel(const RotEntry *__restrict__ tab, int k, int parity) {
+    const RotEntry e = tab[blockIdx.z];
+    const long long n4 = (long long)e.H * e.C / 4;
+    const float4 *src = reinterpret_cast<const float4 *>(e.buf[parity] + (long long)blockIdx.y * e.bs +
+                                                         (long long)k * e.rate * e.C);
+    float4 *dst = reinterpret_cast<float4 *>(e.buf[parity ^ 1] + (long long)blockIdx.y * e.bs);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void stream_rows_in_kernel(const float *__restrict__ src, long long src_bs,
+                                                             float *__restrict__ dst, long long dst_bs, long long n) {
+    const float *s = src + (long long)blockIdx.y * src_bs;
+    float *d = dst + (long long)blockIdx.y * dst_bs;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) d[i] = s[i];
+}
+
+}  // namespace
+
+struct bvc_vocoder_stream {
+    const bvc_model *m = nullptr;
+    int B = 0, kmax = 0, parity = 0;
+    int64_t frames = 0;
+    float *pool = nullptr;
+    size_t pool_floats = 0;
+    RotEntry *d_tab = nullptr;
+    int n_ten = 0, max_hc4 = 0;
+    StreamTensor mel, y0;
+    std::vector<StreamTensor> X, XS;                  // per stage
+    std::vector<StreamTensor> P, Q;                   // per (stage, AMP block): each block's intermediates keep their own history
+    ~bvc_vocoder_stream() {
+        if (pool) (void)hipFree(pool);
+        if (d_tab) (void)hipFree(d_tab);
+    }
+};
+
+namespace {
+
+const int STREAM_H = 64;     // history rows per stage: >= (ks-1)*dil + (ks-1) of every AMP pair (max 60) and a multiple of every rate
+
+int stream_push(bvc_vocoder_stream *st, const float *d_mel, int k, float div, float *d_wav, hipStream_t s) {
+    const bvc_model *m = st->m;
+    const bvc_config &c = m->cfg;
+    const int B = st->B, p = st->parity;
+    int rc;
+    auto bs = [](const StreamTensor &t) { return t.rows * t.C; };
+    // new mel rows behind the history
+    stream_rows_in_kernel<<<dim3((unsigned)((k * st->mel.C + 255) / 256), B), 256, 0, s>>>(
+        d_mel, (long long)k * st->mel.C, st->mel.buf[p] + (long long)st->mel.H * st->mel.C, bs(st->mel), (long long)k * st->mel.C);
+    BVC_HIP_TRY(hipGetLastError());
+    // conv_pre: mel rows [Hm, Hm+k) -> y0 rows [Hy, Hy+k)
+    {
+        ConvWindow w{bs(st->mel), bs(st->y0), st->mel.H, 0};
+        float *out = st->y0.buf[p] + (long long)(st->y0.H - st->mel.H) * st->y0.C;
+        if ((rc = launch_conv_mfma(m->conv_pre, st->mel.buf[p], st->mel.H + k, out, st->mel.H + k, B, CE_STORE, nullptr,
+                                   nullptr, 1.0f, s, &w))) return rc;
+    }
+    const StreamTensor *prev = &st->y0;
+    long long rate_prev = 1;
+    for (int i = 0; i < c.n_up; ++i) {
+        const int u = c.up_rates[i];
+        const StreamTensor &X = st->X[i], &XS = st->XS[i];
+        // transposed conv as a 2-tap conv over the view (rows/u, u*C): view row q <-> X rows [u*q, u*q+u)
+        {
+            const long long hq = X.H / u;                              // history rows of the view
+            const long long nq = rate_prev * k;                        // new view rows
+            ConvWindow w{bs(*prev), bs(X), hq, 0};
+            const float *in = prev->buf[p] + (long long)(prev->H - hq) * prev->C;
+            if ((rc = launch_conv_mfma(m->ups[i], in, hq + nq, X.buf[p], hq + nq, B, CE_STORE, nullptr, nullptr, 1.0f, s, &w))) return rc;
+        }
+        const long long L = X.H + (long long)X.rate * k;
+        ConvWindow w{bs(X), bs(X), X.H, (long long)X.rate * st->frames - X.H};
+        for (int j = 0; j < c.n_resk; ++j) {
+            const StreamTensor &P = st->P[i * c.n_resk + j], &Q = st->Q[i * c.n_resk + j];
+            const float *cur = X.buf[p];
+            for (int d = 0; d < 3; ++d) {
+                const AmpPair &ap = m->amp[i][j][d];
+                float *dst;
+                int epi = CE_RES;
+                if (d < 2) dst = (d == 0) ? P.buf[p] : Q.buf[p];
+                else {
+                    dst = XS.buf[p];
+                    epi = (j == 0) ? CE_RES : (j + 1 < c.n_resk ? CE_RES_ACC : CE_RES_ACC_DIV);
+                    if (c.n_resk == 1) epi = CE_RES;
+                }
+                if ((rc = launch_amp_pair(ap.c1, ap.c2, cur, L, dst, B, epi, XS.buf[p], (float)c.n_resk, s, &w))) return rc;
+                cur = dst;
+            }
+        }
+        prev = &XS;
+        rate_prev = X.rate;
+    }
+    {
+        ConvWindow w{bs(*prev), 0, prev->H, 0};
+        if ((rc = launch_conv_post(prev->buf[p], prev->H + rate_prev * k, m->post_c, m->post_ks, m->post_w, m->post_b,
+                                   m->post_a, m->post_ib, div, d_wav, rate_prev * k, B, s, &w))) return rc;
+    }
+    stream_rotate_kernel<<<dim3((unsigned)((st->max_hc4 + 255) / 256), B, st->n_ten), 256, 0, s>>>(st->d_tab, k, p);
+    BVC_HIP_TRY(hipGetLastError());
+    st->parity ^= 1;
+    st->frames += k;
+    return BVC_OK;
+}
+
 __global__ void tap_copy_kernel(const float *src, float *dst, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         dst[i] = src[i];
@@ -964,6 +1076,81 @@ int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, i
     hipStream_t s = (hipStream_t)stream;
     if ((rc = run_decode(m, w, d_ws, d_codes, nullptr, B, T, w.mel, nullptr, s))) return rc;
     return run_vocoder(m, w, w.mel, B, T, length, out_scale_div, d_wav, -1, nullptr, nullptr, nullptr, s);
+}
+
+int bvc_vocoder_stream_create(const bvc_model *m, int32_t B, int32_t max_frames_per_push, bvc_vocoder_stream **out) {
+    if (!m || !out || B <= 0 || max_frames_per_push <= 0) { set_error("bvc_vocoder_stream_create: bad arguments"); return BVC_EINVAL; }
+    const bvc_config &c = m->cfg;
+    // the history must cover every receptive field and stay aligned with the transposed-conv views
+    long long rate = 1;
+    for (int i = 0; i < c.n_up; ++i) {
+        const int u = c.up_rates[i];
+        if (STREAM_H % u) { set_error("streaming vocoder: upsample rate %d does not divide the history (%d)", u, STREAM_H); return BVC_EINVAL; }
+        for (int j = 0; j < c.n_resk; ++j)
+            for (int d = 0; d < 3; ++d) {
+                const AmpPair &ap = m->amp[i][j][d];
+                if ((ap.c1.ks - 1) * ap.c1.dil + (ap.c2.ks - 1) * ap.c2.dil > STREAM_H) {
+                    set_error("streaming vocoder: AMP receptive field exceeds the history"); return BVC_EINVAL;
+                }
+            }
+        rate *= u;
+    }
+    if (m->post_ks - 1 > STREAM_H) { set_error("streaming vocoder: conv_post kernel exceeds the history"); return BVC_EINVAL; }
+    std::unique_ptr<bvc_vocoder_stream> st(new bvc_vocoder_stream());
+    st->m = m; st->B = B; st->kmax = max_frames_per_push;
+    auto mk = [&](int C, int H, int r) { StreamTensor t; t.buf[0] = t.buf[1] = nullptr; t.C = C; t.H = H; t.rate = r; t.rows = H + (long long)r * max_frames_per_push; return t; };
+    st->mel = mk(c.num_mels, (m->conv_pre.ks - 1) * m->conv_pre.dil, 1);
+    st->y0 = mk(c.upsample_initial_channel, STREAM_H / c.up_rates[0], 1);
+    if (st->y0.H < st->mel.H) st->y0.H = st->mel.H, st->y0.rows = st->y0.H + max_frames_per_push;
+    rate = 1;
+    for (int i = 0; i < c.n_up; ++i) {
+        rate *= c.up_rates[i];
+        for (auto *v : {&st->X, &st->XS}) v->push_back(mk(m->stage_ch[i], STREAM_H, (int)rate));
+        for (int j = 0; j < c.n_resk; ++j)
+            for (auto *v : {&st->P, &st->Q}) v->push_back(mk(m->stage_ch[i], STREAM_H, (int)rate));
+    }
+    std::vector<StreamTensor *> all = {&st->mel, &st->y0};
+    for (auto *v : {&st->X, &st->XS, &st->P, &st->Q})
+        for (auto &t : *v) all.push_back(&t);
+    size_t total = 0;
+    for (auto *t : all) total += 2 * (size_t)B * t->rows * t->C;
+    if (hipMalloc(reinterpret_cast<void **>(&st->pool), total * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("streaming vocoder: cannot allocate %zu bytes of history buffers", total * sizeof(float));
+        return BVC_ENOMEM;
+    }
+    st->pool_floats = total;
+    size_t off = 0;
+    std::vector<RotEntry> tab;
+    for (auto *t : all) {
+        for (int q = 0; q < 2; ++q) { t->buf[q] = st->pool + off; off += (size_t)B * t->rows * t->C; }
+        RotEntry e; e.buf[0] = t->buf[0]; e.buf[1] = t->buf[1]; e.bs = t->rows * t->C; e.C = t->C; e.H = t->H; e.rate = t->rate; e.pad_ = 0;
+        tab.push_back(e);
+        if ((t->H * t->C) % 4) { set_error("streaming vocoder: history of a tensor is not a multiple of 4 floats"); return BVC_EINVAL; }
+        st->max_hc4 = std::max(st->max_hc4, t->H * t->C / 4);
+    }
+    st->n_ten = (int)tab.size();
+    BVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&st->d_tab), tab.size() * sizeof(RotEntry)));
+    BVC_HIP_TRY(hipMemcpy(st->d_tab, tab.data(), tab.size() * sizeof(RotEntry), hipMemcpyHostToDevice));
+    BVC_HIP_TRY(hipMemset(st->pool, 0, total * sizeof(float)));
+    *out = st.release();
+    return BVC_OK;
+}
+
+void bvc_vocoder_stream_destroy(bvc_vocoder_stream *st) { delete st; }
+
+int bvc_vocoder_stream_reset(bvc_vocoder_stream *st, void *stream) {
+    if (!st) { set_error("null stream state"); return BVC_EINVAL; }
+    BVC_HIP_TRY(hipMemsetAsync(st->pool, 0, st->pool_floats * sizeof(float), (hipStream_t)stream));
+    st->parity = 0; st->frames = 0;
+    return BVC_OK;
+}
+
+int bvc_vocoder_stream_push(bvc_vocoder_stream *st, const float *d_mel, int32_t k, float out_scale_div, float *d_wav,
+                            void *stream) {
+    if (!st || !d_mel || !d_wav) { set_error("null argument"); return BVC_EINVAL; }
+    if (k <= 0 || k > st->kmax) { set_error("bvc_vocoder_stream_push: k=%d outside 1..%d", (int)k, st->kmax); return BVC_EINVAL; }
+    return stream_push(st, d_mel, k, out_scale_div, d_wav, (hipStream_t)stream);
 }
 
 int bvc_probe_begin(int32_t kind, int32_t sample_every, int32_t max_samples) {

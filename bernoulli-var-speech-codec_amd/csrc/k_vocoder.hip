@@ -29,6 +29,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct ConvArgs {
     const float *in;  long long Lin;
     float *out;       long long Lout;
+    long long in_bs, out_bs;      // floats between consecutive batch items of in / out (res, acc like out)
+    long long row_begin;          // first output row to compute (rows before it are history: streaming)
     const float *res; const float *acc;
     const float *wp;  const float *bias;
     const float *act_a; const float *act_ib;
@@ -69,13 +71,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.tiles_per_batch;
-    const long long t0 = (long long)(blockIdx.x % a.tiles_per_batch) * TT;
+    const long long t0 = a.row_begin + (long long)(blockIdx.x % a.tiles_per_batch) * TT;
     const int ntile0 = blockIdx.y * NTW;
     const int halo = (a.ks - 1) * a.dil;
     const int rows = TT + halo;
 
     // ---- stage the activated input span [t0-halo, t0+TT) in LDS
-    const float *inb = a.in + (long long)b * a.Lin * CIN;
+    const float *inb = a.in + (long long)b * a.in_bs;
     for (int idx = tid; idx < rows * C4; idx += 256) {
         const int row = idx / C4, c4 = idx - row * C4;
         const long long tg = t0 - halo + row;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: D[row = g*4+e][col = r]
-    const long long ob = (long long)b * a.Lout;
+    const long long ob = (long long)b * a.out_bs;
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
         const int col = (ntile0 + n) * 16 + r;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             for (int e = 0; e < 4; ++e) {
                 const long long t = t0 + mbase + i * 16 + g * 4 + e;
                 if (t >= a.Lout) continue;
-                const long long o = (ob + t) * a.cout + col;
+                const long long o = ob + t * a.cout + col;
                 float v = acc[i][n][e] + bias;
                 if (a.epi >= CE_RES) v = v + a.res[o];               // x = xt + x      (models.py:119)
                 if (a.epi >= CE_RES_ACC) v = a.acc[o] + v;           // xs += resblock  (models.py:224)
@@ -172,6 +174,9 @@ struct AmpArgs {
     const float *w2, *b2, *a2, *ib2;
     float divisor;
     int epi, ks, dil, tiles_per_batch;
+    long long bs;                 // floats between batch items of x / out / acc
+    long long row_begin;          // first output row (streaming: rows before it are history)
+    long long t_origin;           // global time of buffer row 0 (streaming); 0 offline
 };
 
 template <int C, int MT>
@@ -188,12 +193,12 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
     const int ks = a.ks, dil = a.dil;
     const int TT = TR - (ks - 1);                          // valid output rows of this workgroup
     const int b = blockIdx.x / a.tiles_per_batch;
-    const long long t0 = (long long)(blockIdx.x % a.tiles_per_batch) * TT;
+    const long long t0 = a.row_begin + (long long)(blockIdx.x % a.tiles_per_batch) * TT;
     const int halo1 = (ks - 1) * dil;
     const int rows1 = TR + halo1;                          // S1(x) rows [t0-(ks-1)-halo1, t0-(ks-1)+TR)
     float *t1 = lds;
     float *t2 = lds + rows1 * S;                           // S2(u) rows [t0-(ks-1), t0-(ks-1)+TR) (+ ks-1 spare)
-    const float *xb = a.x + (long long)b * a.L * C;
+    const float *xb = a.x + (long long)b * a.bs;
     const long long tbase = t0 - (ks - 1);                 // global row of local row 0 of phase 2 / t2
 
     // ---- phase 1: activated input span.  All global loads of the span are issued before the first
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
                 for (int e = 0; e < 4; ++e) {
                     const int row = mbase + i * 16 + g * 4 + e;
                     const float u = acc[i][n][e] + bias;
-                    t2[row * S + col] = (tbase + row >= 0) ? snakebeta(u, aa, bb) : 0.0f;
+                    t2[row * S + col] = (tbase + row + a.t_origin >= 0) ? snakebeta(u, aa, bb) : 0.0f;
                 }
         }
     }
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
     // ---- phase 3: x' = conv2(t2) + b2 + x   (+ running sum over the AMP blocks, / num_kernels)
     // The residual (and running-sum) operands are fetched BEFORE the MFMA loop so that their latency is
     // covered by it instead of being exposed in the epilogue.
-    const long long ob = (long long)b * a.L;
+    const long long ob = (long long)b * a.bs;
     float resv[MT][NT][4], accv[MT][NT][4];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
                 const int row = mbase + i * 16 + g * 4 + e;
                 const long long t = t0 + row;
                 const bool ok = col < C && row < TT && t < a.L;
-                const long long o = (ob + (ok ? t : 0)) * C + (ok ? col : 0);
+                const long long o = ob + (ok ? t : 0) * C + (ok ? col : 0);
                 resv[i][n][e] = ok ? a.x[o] : 0.0f;
                 accv[i][n][e] = (ok && a.epi >= CE_RES_ACC) ? a.acc[o] : 0.0f;
             }
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
                 const int row = mbase + i * 16 + g * 4 + e;
                 const long long t = t0 + row;
                 if (row >= TT || t >= a.L) continue;
-                const long long o = (ob + t) * C + col;
+                const long long o = ob + t * C + col;
                 float v = acc[i][n][e] + bias;
                 v = v + resv[i][n][e];                               // x = xt + x      (models.py:119)
                 if (a.epi >= CE_RES_ACC) v = accv[i][n][e] + v;      // xs += resblock  (models.py:224)
@@ -338,7 +343,8 @@ template <int C, int MT>
 static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
     constexpr int TR = 4 * MT * 16;
     const int TT = TR - (a.ks - 1);
-    a.tiles_per_batch = (int)((a.L + TT - 1) / TT);
+    a.tiles_per_batch = (int)((a.L - a.row_begin + TT - 1) / TT);
+    if (a.tiles_per_batch <= 0) return BVC_OK;
     const size_t lds = (size_t)((TR + (a.ks - 1) * a.dil) + TR + (a.ks - 1)) * (C + 2) * sizeof(float);
     if (lds > 160 * 1024 || TT <= 0) { set_error("amp_pair tile needs %zu B of LDS", lds); return BVC_EINVAL; }
     ProbeScope probe(PK_CONV, s);
@@ -348,7 +354,7 @@ static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
 }
 
 int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, long long L, float *out, int B, int epi,
-                    const float *acc, float divisor, hipStream_t s) {
+                    const float *acc, float divisor, hipStream_t s, const ConvWindow *win) {
     if (B <= 0 || L <= 0) return BVC_OK;
     if (c1.cin != c1.cout || c2.cin != c1.cin || c2.ks != c1.ks || c2.dil != 1 || !c1.act_a || !c2.act_a) {
         set_error("amp_pair: unsupported layer pair");
@@ -359,6 +365,9 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
     a.w1 = c1.wp; a.b1 = c1.bias; a.a1 = c1.act_a; a.ib1 = c1.act_ib;
     a.w2 = c2.wp; a.b2 = c2.bias; a.a2 = c2.act_a; a.ib2 = c2.act_ib;
     a.divisor = divisor; a.epi = epi; a.ks = c1.ks; a.dil = c1.dil; a.tiles_per_batch = 0;
+    a.bs = win ? win->in_bs : L * c1.cin;
+    a.row_begin = win ? win->row_begin : 0;
+    a.t_origin = win ? win->t_origin : 0;
     switch (c1.cin) {
         case 64: return launch_amp_t<64, 1>(a, B, s);
         case 32: return launch_amp_t<32, 2>(a, B, s);
@@ -372,7 +381,8 @@ template <int CIN, int NTW, int MT>
 static int launch_one(const ConvArgs &a, int B, hipStream_t s) {
     constexpr int TT = 4 * MT * 16;
     ConvArgs k = a;
-    k.tiles_per_batch = (int)((a.Lout + TT - 1) / TT);
+    k.tiles_per_batch = (int)((a.Lout - a.row_begin + TT - 1) / TT);
+    if (k.tiles_per_batch <= 0) return BVC_OK;
     const size_t lds = (size_t)(TT + (a.ks - 1) * a.dil) * (CIN + 2) * sizeof(float);
     if (lds > 160 * 1024) { set_error("conv tile needs %zu B of LDS", lds); return BVC_EINVAL; }
     dim3 grid((unsigned)(k.tiles_per_batch * (long long)B), (unsigned)((a.ntiles + NTW - 1) / NTW));
@@ -408,10 +418,13 @@ int conv_kernels_init() {
 }
 
 int launch_conv_mfma(const ConvLayer &c, const float *in, long long Lin, float *out, long long Lout, int B,
-                     int epi, const float *res, const float *acc, float divisor, hipStream_t s) {
+                     int epi, const float *res, const float *acc, float divisor, hipStream_t s, const ConvWindow *win) {
     if (B <= 0 || Lout <= 0) return BVC_OK;
     ConvArgs a;
     a.in = in; a.Lin = Lin; a.out = out; a.Lout = Lout; a.res = res; a.acc = acc;
+    a.in_bs = win ? win->in_bs : Lin * c.cin;
+    a.out_bs = win ? win->out_bs : Lout * c.cout;
+    a.row_begin = win ? win->row_begin : 0;
     a.wp = c.wp; a.bias = c.bias; a.act_a = c.act_a; a.act_ib = c.act_ib;
     a.divisor = divisor; a.epi = epi; a.ks = c.ks; a.dil = c.dil; a.cout = c.cout; a.ntiles = c.ntiles;
     a.tiles_per_batch = 0;
@@ -437,13 +450,13 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float *__restrict_
                                                         const float *__restrict__ act_a,
                                                         const float *__restrict__ act_ib, float div,
                                                         float *__restrict__ wav, long long n_out,
-                                                        int tiles_per_batch) {
+                                                        int tiles_per_batch, long long in_bs, long long row_begin) {
     extern __shared__ __attribute__((aligned(16))) float tile[];     // [(256 + ks-1)][C]
     const int tid = threadIdx.x;
     const int b = blockIdx.x / tiles_per_batch;
-    const long long t0 = (long long)(blockIdx.x % tiles_per_batch) * 256;
+    const long long t0 = row_begin + (long long)(blockIdx.x % tiles_per_batch) * 256;     // input row of output 0 of the tile
     const int halo = ks - 1;
-    const float *inb = in + (long long)b * Lin * C;
+    const float *inb = in + (long long)b * in_bs;
     for (int idx = tid; idx < (256 + halo) * C; idx += 256) {
         const int row = idx / C, c = idx - row * C;
         const long long tg = t0 - halo + row;
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float *__restrict_
         tile[idx] = v;
     }
     __syncthreads();
-    const long long t = t0 + tid;
+    const long long t = t0 + tid - row_begin;                        // output sample index
     if (t >= n_out) return;
     float acc = 0.0f;
     for (int j = 0; j < ks; ++j)
@@ -463,14 +476,14 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float *__restrict_
 
 int launch_conv_post(const float *in, long long Lin, int C, int ks, const float *w, const float *bias,
                      const float *act_a, const float *act_ib, float div, float *wav, long long n_out, int B,
-                     hipStream_t s) {
+                     hipStream_t s, const ConvWindow *win) {
     if (B <= 0 || n_out <= 0) return BVC_OK;
     if (C != 8) { set_error("conv_post: unsupported channel count %d", C); return BVC_EINVAL; }
     const int tiles = (int)((n_out + 255) / 256);
     const size_t lds = (size_t)(256 + ks - 1) * C * sizeof(float);
     ProbeScope probe(PK_POST, s);
     hipLaunchKernelGGL(conv_post_kernel<8>, dim3((unsigned)(tiles * (long long)B)), dim3(256), lds, s, in, Lin, ks,
-                       w, bias, act_a, act_ib, div, wav, n_out, tiles);
+                       w, bias, act_a, act_ib, div, wav, n_out, tiles, win ? win->in_bs : Lin * C, win ? win->row_begin : 0);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }

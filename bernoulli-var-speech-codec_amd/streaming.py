@@ -9,17 +9,23 @@ primitives are causal, though, so chunked processing is exact:
   have arrived (algorithmic look-ahead 768 samples = 34.8 ms, README.md:19); the last frames of an
   utterance, which need the right reflect padding, are emitted by ``flush()``;
 * BVRNN: the GRU state is carried from chunk to chunk (``bvc_bvrnn_encode/decode`` take h0, return hT);
-* vocoder: every output sample depends on at most ``CONTEXT_FRAMES`` past mel frames (conv_pre 6 frames
-  + per stage 12*(k-1) = 120 samples of AMP halo + 1 sample of transposed conv), so each hop re-runs
-  the generator over [context | new frames] and keeps the new samples.  (A ring-buffer vocoder that
-  avoids recomputing the context is future work.)
+* vocoder: the generator is causal, so the library keeps the last 64 rows of every activation tensor
+  (``bvc_vocoder_stream_*``, include/bvcodec.h) and a hop computes only the rows of its new frames -
+  256 samples per frame, bit-for-bit the kernels of the offline path.  ``incremental=False`` selects
+  the older, stateless scheme instead: every output sample depends on at most ``CONTEXT_FRAMES`` past
+  mel frames (conv_pre 6 frames + per stage 12*(k-1) = 120 samples of AMP halo + 1 sample of
+  transposed conv), so each hop re-runs the generator over [context | new frames] and keeps the new
+  samples (≈4x the work per 20 ms hop).  The tail beyond the last full frame (``flush``) always uses
+  the context scheme.
 
 ``tests/test_gpu_streaming.py`` checks that any chunking reproduces the offline encode()/decode().
 """
+import ctypes
 import math
 
 import torch
 
+from . import _abi
 from .model import SCALING
 
 CONTEXT_FRAMES = 26      # ceil(6 + 1 + 15 + 1/8 + 120/64 + 1/64 + 120/128 + 1/128 + 120/256 + 6/256)
@@ -79,8 +85,50 @@ class StreamingEncoder:
         return self._emit(total)
 
 
+class VocoderStream:
+    """Handle of the library's incremental generator state for `batch` parallel streams."""
+
+    def __init__(self, engine, batch, max_frames_per_push):
+        self.eng = engine
+        self.B = batch
+        self.kmax = max_frames_per_push
+        self.spf = math.prod(engine.conf["vocoder_config"]["upsample_rates"])
+        h = ctypes.c_void_p()
+        with torch.cuda.device(engine.device):
+            _abi.check(engine.lib.bvc_vocoder_stream_create(engine.handle, batch, max_frames_per_push, ctypes.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.eng.lib.bvc_vocoder_stream_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def reset(self):
+        with torch.cuda.device(self.eng.device):
+            _abi.check(self.eng.lib.bvc_vocoder_stream_reset(self.handle, self.eng.stream()))
+
+    def push(self, mel, scale_div=1.0):
+        """mel (B, k, num_mels) time-major on the engine's device -> wav (B, k*256)."""
+        B, k, _ = mel.shape
+        assert B == self.B
+        out = torch.empty(B, k * self.spf, device=self.eng.device)
+        with torch.cuda.device(self.eng.device):
+            for f in range(0, k, self.kmax):                   # longer chunks go through in kmax-frame pieces
+                n = min(self.kmax, k - f)
+                piece = mel[:, f:f + n].contiguous()
+                dst = out if n == k else torch.empty(B, n * self.spf, device=self.eng.device)
+                _abi.check(self.eng.lib.bvc_vocoder_stream_push(self.handle, _abi.ptr(piece), n, float(scale_div),
+                                                                _abi.ptr(dst), self.eng.stream()))
+                if dst is not out:
+                    out[:, f * self.spf:(f + n) * self.spf] = dst
+        return out
+
+
 class StreamingDecoder:
-    def __init__(self, model, batch, device=None):
+    def __init__(self, model, batch, device=None, incremental=True, max_frames_per_push=8):
         self.m = model
         self.B = batch
         eng = model.engine(None if device is None else torch.empty(0, device=device))
@@ -90,6 +138,7 @@ class StreamingDecoder:
         self.ctx = torch.empty(batch, 0, c["num_mels"], device=self.dev)     # last CONTEXT_FRAMES mel frames
         self.spf = math.prod(c["vocoder_config"]["upsample_rates"])         # samples per frame (256)
         self.tail = None
+        self.voc = VocoderStream(eng, batch, max_frames_per_push) if incremental else None
 
     @torch.no_grad()
     def push(self, codes):
@@ -100,14 +149,21 @@ class StreamingDecoder:
         mel, self.h = self.m.bvrnn.decode(codes.to(self.dev, torch.float32), self.h)
         allmel = torch.cat([self.ctx, mel], 1)
         nctx = self.ctx.shape[1]
+        self.ctx = allmel[:, -CONTEXT_FRAMES:].contiguous()
+        if self.voc is not None:
+            self.tail = None
+            return self.voc.push(mel, SCALING)
         wav = self.m.vocoder(allmel, 10 ** 12, _scale_div=SCALING, _time_major=True)[:, 0]
         out = wav[:, self.spf * nctx: self.spf * (nctx + k)]
         self.tail = wav[:, self.spf * (nctx + k):]             # partial sums beyond the last frame (models.py:238)
-        self.ctx = allmel[:, -CONTEXT_FRAMES:].contiguous()
         return out
 
+    @torch.no_grad()
     def flush(self, n_extra):
         """Up to 294 samples beyond the last full frame (what decode(codes, length) returns past 256*T)."""
-        if self.tail is None:
+        if n_extra <= 0 or self.ctx.shape[1] == 0:
             return torch.empty(self.B, 0, device=self.dev)
+        if self.tail is None:                                  # incremental mode: the tail comes from the context
+            wav = self.m.vocoder(self.ctx, 10 ** 12, _scale_div=SCALING, _time_major=True)[:, 0]
+            self.tail = wav[:, self.spf * self.ctx.shape[1]:]
         return self.tail[:, :max(0, n_extra)]

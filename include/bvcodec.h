@@ -116,6 +116,20 @@ int bvc_bvrnn_decode(const bvc_model *m, const float *d_codes, const float *d_h0
 int bvc_bigvgan(const bvc_model *m, const float *d_mel, int32_t B, int64_t T, int64_t length,
                 float out_scale_div, float *d_wav, void *d_ws, size_t ws_bytes, void *stream);
 
+/* Incremental BigVGAN for streaming (not in the reference, whose BigVGAN.forward, models.py:207-238,
+ * always sees the whole utterance).  The state keeps the last rows of every activation tensor of the
+ * generator for B parallel streams; bvc_vocoder_stream_push runs the generator over only the k new mel
+ * frames d_mel (B,k,num_mels) and writes exactly their samples d_wav (B, k*prod(upsample_rates)),
+ * equal to the corresponding slice of bvc_bigvgan over the whole utterance.  One in-flight push per
+ * state; state buffers are allocated by create (device memory), zeroed by create/reset. */
+typedef struct bvc_vocoder_stream bvc_vocoder_stream;
+int bvc_vocoder_stream_create(const bvc_model *m, int32_t B, int32_t max_frames_per_push,
+                              bvc_vocoder_stream **out);
+void bvc_vocoder_stream_destroy(bvc_vocoder_stream *st);
+int bvc_vocoder_stream_reset(bvc_vocoder_stream *st, void *stream);
+int bvc_vocoder_stream_push(bvc_vocoder_stream *st, const float *d_mel, int32_t k, float out_scale_div,
+                            float *d_wav, void *stream);
+
 /* BVRNNCodecModel.encode (bvrnn_codec_model.py:44-62): scale, log-mel, bits/frame =
  * bits_per_frame for every (b,t), zero initial state, BVRNN.encode.  d_wav (B,L) -> d_codes. */
 int bvc_encode(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, float scale,

@@ -14,8 +14,9 @@ def model():
     return make_model(True, 1024)[0]
 
 
+@pytest.mark.parametrize("incremental", [True, False])
 @pytest.mark.parametrize("hop", [441, 1000, 4096])
-def test_streaming_equals_offline(model, hop):
+def test_streaming_equals_offline(model, hop, incremental):
     from bvcodec import synth
     from bvcodec.streaming import StreamingDecoder, StreamingEncoder
     B, L = 3, 256 * 60 + 123
@@ -24,7 +25,7 @@ def test_streaming_equals_offline(model, hop):
     wav_off = model.decode(codes_off, L)
 
     enc = StreamingEncoder(model, B, 3000)
-    dec = StreamingDecoder(model, B)
+    dec = StreamingDecoder(model, B, incremental=incremental)
     codes, wavs = [], []
     for s in range(0, L, hop):
         c = enc.push(x[:, s:s + hop])
@@ -41,6 +42,35 @@ def test_streaming_equals_offline(model, hop):
     assert wav.shape == wav_off.shape
     err = (wav - wav_off).abs().max().item()
     assert err <= 1e-6, err                                                             # same arithmetic per sample
+
+
+def test_incremental_vocoder_equals_offline_for_any_chunking(model):
+    """bvc_vocoder_stream_push over ragged chunks == the matching slice of bvc_bigvgan over everything;
+    reset() starts a new utterance on the same state."""
+    from bvcodec.streaming import VocoderStream
+    B, T = 2, 57
+    g = torch.Generator().manual_seed(5)
+    mel = (torch.randn(B, T, 80, generator=g) * 1.5 - 4.0).to(DEV)
+    ref = model.vocoder(mel, 10 ** 12, _time_major=True)[:, 0]
+    vs = VocoderStream(model.engine(mel), B, 5)
+    for trial in range(2):
+        chunks, t = [], 0
+        sizes = [1, 5, 2, 1, 1, 4, 3, 5, 5, 5, 5, 5, 5, 5, 5] if trial == 0 else [13, 1, 20, 23]   # >kmax: split inside
+        for k in sizes:
+            k = min(k, T - t)
+            if k == 0:
+                break
+            chunks.append(vs.push(mel[:, t:t + k].contiguous()))
+            t += k
+        assert t == T
+        wav = torch.cat(chunks, 1)
+        assert wav.shape == (B, 256 * T)
+        err = (wav - ref[:, :256 * T]).abs().max().item()
+        assert err <= 1e-6, (trial, err)
+        vs.reset()
+    from bvcodec import _abi
+    with pytest.raises(RuntimeError):                      # more frames than the state was sized for
+        _abi.check(vs.eng.lib.bvc_vocoder_stream_push(vs.handle, _abi.ptr(mel), 6, 1.0, _abi.ptr(ref), vs.eng.stream()))
 
 
 def test_streaming_hop_latency_is_real_time(model):
