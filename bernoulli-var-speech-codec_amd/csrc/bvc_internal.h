@@ -165,6 +165,9 @@ struct ConvLayer {               // one causal conv as implicit GEMM on fp32 MFM
 enum ConvEpi { CE_STORE = 0, CE_RES = 1, CE_RES_ACC = 2, CE_RES_ACC_DIV = 3 };
 // Streaming window: the tensors are (B, rows, C) buffers whose first rows are history; only rows from
 // row_begin on are computed.  t_origin = global time of buffer row 0 (for the zero-before-start rule).
+#ifdef BVC_PHASE_PROBE
+int phase_probe_read(unsigned long long *out, int reset);   // debugging builds only (tools/phase_probe.py)
+#endif
 struct ConvWindow { long long in_bs, out_bs, row_begin, t_origin; };
 // in (B, Lin, cin) channels-last; out (B, Lout, cout).  Output row r reads input rows
 // r - (ks-1)*dil ... r  (rows outside [0,Lin) are zero).  res/acc have the layout of out.

@@ -1153,6 +1153,10 @@ int bvc_vocoder_stream_push(bvc_vocoder_stream *st, const float *d_mel, int32_t 
     return stream_push(st, d_mel, k, out_scale_div, d_wav, (hipStream_t)stream);
 }
 
+#ifdef BVC_PHASE_PROBE
+int bvc_phase_probe_read(unsigned long long *out, int reset) { return bvc::phase_probe_read(out, reset); }
+#endif
+
 int bvc_probe_begin(int32_t kind, int32_t sample_every, int32_t max_samples) {
     if (kind <= PK_NONE || kind > PK_POST || sample_every < 1 || max_samples < 1) {
         set_error("bvc_probe_begin: bad arguments");

@@ -20,6 +20,8 @@
 //      out[q*u + p, co] = b[co] + sum_ci in[q, ci] W[ci, co, p] + in[q-1, ci] W[ci, co, p+u]
 // is a 2-tap causal convolution with u*Cout output columns whose (B, Lin+1, u*Cout) result IS the
 // (B, (Lin+1)*u, Cout) channels-last signal.
+#include <type_traits>
+
 #include "bvc_internal.h"
 
 namespace bvc {
@@ -179,8 +181,17 @@ struct AmpArgs {
     long long t_origin;           // global time of buffer row 0 (streaming); 0 offline
 };
 
+#ifdef BVC_PHASE_PROBE
+__device__ unsigned long long g_phase[16];
+#define PHASE(i) do { if (threadIdx.x == 0) { unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_phase[i], now_ - last_); last_ = now_; } } while (0)
+#else
+#define PHASE(i)
+#endif
 template <int C, int MT>
 __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArgs a) {
+#ifdef BVC_PHASE_PROBE
+    unsigned long long last_ = __builtin_readcyclecounter();
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int S = C + 2;
     constexpr int NT = (C + 15) / 16;
@@ -233,6 +244,7 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
     }
     for (int idx = tid; idx < (ks - 1) * S; idx += 256) t2[TR * S + idx] = 0.0f;    // spare rows read by discarded outputs
     __syncthreads();
+    PHASE(0);
 
     const int mbase = wave * MT * 16;
     f32x4 acc[MT][NT];
@@ -277,8 +289,46 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
         }
     };
 
+    // Narrow stages (C <= 16): a conv's whole weight set is <= 44 fragments per lane, so it is fetched once
+    // into registers and the tap loop is fully unrolled (no per-chunk wait on a weight load; the LDS reads
+    // of later taps are scheduled under the MFMAs of earlier ones).  Same accumulation order as mma().
+    auto mma_small = [&](const float *tile, int d, const float *wp, auto ks_c) {
+        constexpr int KS = decltype(ks_c)::value;
+        static_assert(NT == 1 || KS == 0, "mma_small is for one 16-column tile");
+        float wreg[KS][C4];
+        const float *wl = wp + lane;
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int c = 0; c < C4; ++c) wreg[j][c] = wl[(j * C4 + c) * NT * 64];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const float *arow = tile + (mbase + r + j * d) * S + g;
+#pragma unroll
+            for (int c = 0; c < C4; ++c) {
+                float av[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) av[i] = arow[i * 16 * S + c * 4];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wreg[j][c], acc[i][0], 0, 0, 0);
+            }
+        }
+    };
+    auto conv = [&](const float *tile, int d, const float *wp) {
+        if constexpr (C <= 16) {
+            if (ks == 11) { mma_small(tile, d, wp, std::integral_constant<int, 11>()); return; }
+            if (ks == 7) { mma_small(tile, d, wp, std::integral_constant<int, 7>()); return; }
+            if (ks == 3) { mma_small(tile, d, wp, std::integral_constant<int, 3>()); return; }
+        }
+        mma(tile, d, wp);
+    };
+
     // ---- phase 2: u = conv1(S1(x)) ; t2 = S2(u + b1), zero before the start of the signal
-    mma(t1, dil, a.w1);
+    conv(t1, dil, a.w1);
+    PHASE(1);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int col = n * 16 + r;
@@ -295,28 +345,29 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
         }
     }
     __syncthreads();
+    PHASE(2);
 
     // ---- phase 3: x' = conv2(t2) + b2 + x   (+ running sum over the AMP blocks, / num_kernels)
     // The residual (and running-sum) operands are fetched BEFORE the MFMA loop so that their latency is
     // covered by it instead of being exposed in the epilogue.
-    const long long ob = (long long)b * a.bs;
-    float resv[MT][NT][4], accv[MT][NT][4];
+    // The rows of a workgroup are consecutive and C is the whole row, so its output (and the residual /
+    // running-sum operands) is ONE contiguous span of global memory: it is moved as float4 per lane, with
+    // the conv2 result transposed from the MFMA layout through LDS (the S1(x) tile is dead by now).
+    const long long ob = (long long)b * a.bs + t0 * C;
+    constexpr int NLD3 = (TR * C4 + 255) / 256;
+    const long long rows_left = a.L - t0;
+    const int nvalid4 = (int)(rows_left < TT ? rows_left : TT) * C4;
+    f32x4 resq[NLD3], accq[NLD3];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int col = n * 16 + r;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = mbase + i * 16 + g * 4 + e;
-                const long long t = t0 + row;
-                const bool ok = col < C && row < TT && t < a.L;
-                const long long o = ob + (ok ? t : 0) * C + (ok ? col : 0);
-                resv[i][n][e] = ok ? a.x[o] : 0.0f;
-                accv[i][n][e] = (ok && a.epi >= CE_RES_ACC) ? a.acc[o] : 0.0f;
-            }
+    for (int i = 0; i < NLD3; ++i) {
+        const int idx = tid + i * 256;
+        const bool ok = idx < nvalid4;
+        resq[i] = ok ? reinterpret_cast<const f32x4 *>(a.x + ob)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        accq[i] = (ok && a.epi >= CE_RES_ACC) ? reinterpret_cast<const f32x4 *>(a.acc + ob)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    mma(t2, 1, a.w2);
+    PHASE(3);
+    conv(t2, 1, a.w2);
+    PHASE(4);
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int col = n * 16 + r;
@@ -325,18 +376,27 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = mbase + i * 16 + g * 4 + e;
-                const long long t = t0 + row;
-                if (row >= TT || t >= a.L) continue;
-                const long long o = ob + t * C + col;
-                float v = acc[i][n][e] + bias;
-                v = v + resv[i][n][e];                               // x = xt + x      (models.py:119)
-                if (a.epi >= CE_RES_ACC) v = accv[i][n][e] + v;      // xs += resblock  (models.py:224)
-                if (a.epi == CE_RES_ACC_DIV) v = v / a.divisor;      // xs / num_kernels (models.py:225)
-                a.out[o] = v;
-            }
+            for (int e = 0; e < 4; ++e) t1[(mbase + i * 16 + g * 4 + e) * S + col] = acc[i][n][e] + bias;
     }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NLD3; ++i) {
+        const int idx = tid + i * 256;
+        if (idx >= nvalid4) continue;
+        const int row = idx / C4, c4 = idx - row * C4;
+        const float2 lo = *reinterpret_cast<const float2 *>(t1 + row * S + c4 * 4);
+        const float2 hi = *reinterpret_cast<const float2 *>(t1 + row * S + c4 * 4 + 2);
+        f32x4 v = (f32x4){lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float o = v[e] + resq[i][e];                             // x = xt + x      (models.py:119)
+            if (a.epi >= CE_RES_ACC) o = accq[i][e] + o;             // xs += resblock  (models.py:224)
+            if (a.epi == CE_RES_ACC_DIV) o = o / a.divisor;          // xs / num_kernels (models.py:225)
+            v[e] = o;
+        }
+        reinterpret_cast<f32x4 *>(a.out + ob)[idx] = v;
+    }
+    PHASE(5);
 }
 
 template <int C, int MT>
@@ -488,4 +548,11 @@ int launch_conv_post(const float *in, long long Lin, int C, int ks, const float 
     return BVC_OK;
 }
 
+#ifdef BVC_PHASE_PROBE
+int phase_probe_read(unsigned long long *out, int reset) {
+    BVC_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {0}; BVC_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z))); }
+    return BVC_OK;
+}
+#endif
 }  // namespace bvc
