@@ -46,6 +46,8 @@ SIGNATURES = {
     "bvc_stft_logmel": (ctypes.c_int, [_vp, _vp, _i32, _i64, _f, _vp, _vp]),
     "bvc_bvrnn_encode": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "bvc_bvrnn_decode": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "bvc_bvrnn_forward": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp,
+                                         _vp, _sz, _vp]),
     "bvc_bigvgan": (ctypes.c_int, [_vp, _vp, _i32, _i64, _i64, _f, _vp, _vp, _sz, _vp]),
     "bvc_vocoder_stream_create": (ctypes.c_int, [_vp, _i32, _i32, ctypes.POINTER(_vp)]),
     "bvc_vocoder_stream_destroy": (None, [_vp]),

@@ -35,7 +35,8 @@ struct ProbeScope {
 // into a hipGraph and replayed for every frame, so nothing that changes per call or per frame may be a
 // kernel argument: caller tensors are reached through this descriptor and the frame index `t` is a
 // device-side counter advanced by step_advance_kernel at the end of every step.
-enum DescSlot { DS_PX = 0, DS_CODES = 1, DS_BITS = 2, DS_PROB = 3, DS_ALLH = 4, DS_MEL = 5, DS_PZ = 6, DS_NSLOT = 8 };
+enum DescSlot { DS_PX = 0, DS_CODES = 1, DS_BITS = 2, DS_PROB = 3, DS_ALLH = 4, DS_MEL = 5, DS_PZ = 6, DS_NOISE = 7, DS_NSLOT = 8,
+                DS_PRIOR = DS_ALLH /* BVRNN.forward has no all_h output: the slot carries the prior probabilities */ };
 struct CallDesc {
     float *p[DS_NSLOT];              // base pointers of the (B, T, dim) tensors of this call (may be null)
     long long T;                     // frames per utterance
@@ -83,8 +84,15 @@ enum GemmEpi {
     EPI_CODE = 2,        // p = sigmoid(acc+bias); z = rint(p); masked by bits  (bvrnn.py:189-194)
     EPI_MEL = 3,         // y = acc + bias (mel frame) ; y2 = (y - mean) / std  (bvrnn.py:202-204)
     EPI_GRU = 4,         // PyTorch GRU cell, 3 gates x 2 groups (whole cell in one launch)
-    EPI_GRU_PART = 5     // GRU cell whose hidden part and phi_z part were pre-computed on the side branch:
+    EPI_GRU_PART = 5,    // GRU cell whose hidden part and phi_z part were pre-computed on the side branch:
                          //   gi = acc + y2part (W_ih[:, H:] phi_z + b_ih), gh = y3part (W_hh h + b_hh)
+    EPI_SIGMOID = 6      // y = sigmoid(acc + bias)   (prior net, bvrnn.py:68-73)
+};
+// EPI_CODE variants (GemmParams::sample): what is rounded and which value z takes
+enum CodeSample {
+    CS_ENCODE = 0,       // z = round(p)                              BVRNN.encode (bvrnn.py:191)
+    CS_GREEDY = 1,       // z = (round(p) - p) + p                    BVRNN.forward greedy (bvrnn.py:124), straight-through value
+    CS_SAMPLE = 2        // z = (round((u - 0.5) + p) - p) + p        Bernoulli sampler (bvrnn.py:126), u from y2
 };
 
 // The first 16 dwords (M .. seg[0].x) hold everything a layer needs to map its tile and issue the operand
@@ -98,9 +106,11 @@ struct GemmParams {
     GemmSeg seg[3];
     int     nseg;
     int     var_bit;
+    int     sample;            // EPI_CODE: CodeSample
+    int     pad_;
     const float *bias0;        // group 0 bias [gates*N] (may be null)
     const float *bias1;        // group 1 bias (GRU only)
-    DynPtr  y, y2, y3;         // outputs (y2/y3 optional)
+    DynPtr  y, y2, y3;         // outputs (y2/y3 optional); EPI_CODE with CS_SAMPLE: y2 = uniform noise INPUT
     DynPtr  aux;               // CODE: bits per frame (one per row); GRU: previous h; ELU: optional addend
     const float *part_i; const float *part_h; long long ldpart;   // GRU_PART: side-branch partial sums [M][3H]
     const float *mean; const float *stdv; // MEL epilogue
@@ -124,6 +134,9 @@ int launch_gemm_batched(const float *x, long long ldx, const float *w, long long
 int launch_normalize_rows(const float *y, const float *mean, const float *stdv, long long rows, int n,
                           float *out, hipStream_t s);
 int launch_fill(float *p, float v, long long n, hipStream_t s);
+// per-frame KL term of BVRNN.forward (bvrnn.py:148-157): kld[t] = mean_b sum_j mask * elem(prob, prior)
+int launch_kld_frames(const float *prob, const float *prior, const float *bits, int B, long long T, int Z, float *kld,
+                      hipStream_t s);
 int launch_copy_rows(const float *src, long long lds, float *dst, long long ldd, int rows, int n, hipStream_t s);
 // natural [rows][n] (row stride ld) <-> fragment-packed [rows/16][n/16][64][4]; dir 0: pack, 1: unpack
 int launch_repack_rows(const float *src, float *dst, long long ld_natural, int rows, int n, int dir, hipStream_t s);

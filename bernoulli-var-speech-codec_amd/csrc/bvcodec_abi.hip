@@ -66,6 +66,8 @@ struct bvc_model {
     // BVRNN
     const float *mean_mel = nullptr, *std_mel = nullptr;
     Linear phi_x[3], phi_z[3], enc[3], dec[4];
+    Linear prior[3];            // only used by bvc_bvrnn_forward; optional (has_prior)
+    bool has_prior = false;
     const float *w_ih = nullptr, *w_hh = nullptr, *b_ih = nullptr, *b_hh = nullptr;     // w_*: fragment-packed
     // vocoder
     ConvLayer conv_pre;
@@ -278,6 +280,12 @@ int build_bvrnn(bvc_model *m, const TensorMap &tm) {
     }
     for (int i = 0; i < 4; ++i)
         if ((rc = load_linear(m, tm, "dec." + std::to_string(2 * i), de_in[i], de_out[i], &m->dec[i]))) return rc;
+    if (tm.count("prior.0.weight")) {        // training-time prior net (bvrnn.py:68-73): needed by bvc_bvrnn_forward only
+        const int pr_out[3] = {H, H, Z};
+        for (int i = 0; i < 3; ++i)
+            if ((rc = load_linear(m, tm, "prior." + std::to_string(2 * i), H, pr_out[i], &m->prior[i]))) return rc;
+        m->has_prior = true;
+    }
     if (!(t = find(tm, "rnn.weight_ih_l0", (int64_t)3 * H * 2 * H))) return BVC_EMISSING;
     if ((rc = upload(m, pack_linear(t->h_data, 3 * H, 2 * H), &m->w_ih))) return rc;
     if (!(t = find(tm, "rnn.weight_hh_l0", (int64_t)3 * H * H))) return BVC_EMISSING;
@@ -787,6 +795,123 @@ int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     return BVC_OK;
 }
 
+// ---- BVRNN.forward (bvrnn.py:86-160): the training-time pass, forward values only --------------------
+// One frame conditioned on state `sel` (0: h, the teacher-forced state; 1: h2, the state fed with generated
+// features).  h2 lives in part_i (the side-branch buffer, unused here), both states ping-pong by frame parity.
+std::vector<StepNode> build_forward_step(const bvc_model *m, const Workspace &w, int B, int sel, bool greedy,
+                                         bool update_h, bool update_h2) {
+    const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
+    std::vector<StepNode> plan;
+    const long long MH = (long long)((B + 15) / 16) * 16 * H;
+    float *hb[2] = {w.hbuf, w.part_i};
+    auto cur = [&](int which) { return dp_parity(hb[which], H, MH, 0, 1); };
+    auto nxt = [&](int which) { return dp_parity(hb[which] + MH, H, -MH, 0, 1); };
+    float *e1 = w.step[0], *e2 = w.step[1];
+    float *pz1 = w.step[2], *pz2 = w.step[3], *pz3 = w.step[4];
+    float *d1 = w.step[5], *d2 = w.step[6], *d3 = w.step[7], *dn = w.step[8];
+    float *g1 = w.step[9], *g2 = w.step[10], *g3 = w.step[11];
+    float *q1 = w.step[12], *q2 = w.step[13];
+    auto S = [&](float *p, int ld) { return dp_static(p, ld, 1); };
+    int node = 0;
+    auto K = [&](GemmParams p, int epi) {
+        p.desc = w.desc; p.node = node++; p.probe = nullptr;
+        finish(p);
+        plan.push_back(StepNode{OP_KERNEL, BR_MAIN, -1, p, epi});
+    };
+    const DynPtr hs = cur(sel);
+    // enc_t and the sample (bvrnn.py:115-129)
+    K(lin2_params(m->enc[0], dp_frame(DS_PX, H, 0, 1), H, hs, H, B, S(e1, H)), EPI_ELU);
+    K(lin_params(m->enc[1], S(e1, H), B, S(e2, H)), EPI_ELU);
+    {
+        GemmParams p = lin_params(m->enc[2], S(e2, H), B, dp_frame(DS_CODES, Z));
+        p.var_bit = m->cfg.var_bit;
+        p.sample = greedy ? CS_GREEDY : CS_SAMPLE;
+        p.aux = dp_frame(DS_BITS, 1);
+        p.y2 = greedy ? dp_null() : dp_frame(DS_NOISE, Z);
+        p.y3 = dp_frame(DS_PROB, Z);
+        K(p, EPI_CODE);
+    }
+    // prior_t (bvrnn.py:116,119)
+    K(lin_params(m->prior[0], hs, B, S(q1, H)), EPI_ELU);
+    K(lin_params(m->prior[1], S(q1, H), B, S(q2, H)), EPI_ELU);
+    K(lin_params(m->prior[2], S(q2, H), B, dp_frame(DS_PRIOR, Z)), EPI_SIGMOID);
+    // phi_z, dec (bvrnn.py:131-137)
+    K(lin_params(m->phi_z[0], dp_frame(DS_CODES, Z), B, S(pz1, H)), EPI_ELU);
+    K(lin_params(m->phi_z[1], S(pz1, H), B, S(pz2, H)), EPI_ELU);
+    K(lin_params(m->phi_z[2], S(pz2, H), B, S(pz3, H)), EPI_ELU);
+    K(lin2_params(m->dec[0], S(pz3, H), H, hs, H, B, S(d1, H)), EPI_ELU);
+    K(lin_params(m->dec[1], S(d1, H), B, S(d2, H)), EPI_ELU);
+    K(lin_params(m->dec[2], S(d2, H), B, S(d3, H)), EPI_ELU);
+    {
+        GemmParams p = lin_params(m->dec[3], S(d3, H), B, dp_frame(DS_MEL, X));
+        p.y2 = S(dn, X); p.mean = m->mean_mel; p.stdv = m->std_mel;
+        K(p, EPI_MEL);
+    }
+    auto gru = [&](DynPtr xin, int which) {
+        GemmParams p;
+        memset(&p, 0, sizeof(p));
+        p.M = B; p.N = H; p.gate_rows = H;
+        p.y = nxt(which);
+        p.y2 = dp_null();
+        p.aux = cur(which);
+        p.nseg = 3;
+        p.seg[0] = mkseg(xin, m->w_ih, 2 * H / 16, H, 0);
+        p.seg[1] = mkseg(S(pz3, H), m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0);
+        p.seg[2] = mkseg(cur(which), m->w_hh, H / 16, H, 1);
+        p.bias0 = m->b_ih; p.bias1 = m->b_hh;
+        K(p, EPI_GRU);
+    };
+    if (update_h) gru(dp_frame(DS_PX, H, 0, 1), 0);                 // h  <- GRU([phi_x_t, phi_z_t], h)      bvrnn.py:142-143
+    if (update_h2) {                                                 // h2 <- GRU([phi_x_t_gen, phi_z_t], h2) bvrnn.py:139,144-145
+        K(lin_params(m->phi_x[0], S(dn, X), B, S(g1, H)), EPI_ELU);
+        K(lin_params(m->phi_x[1], S(g1, H), B, S(g2, H)), EPI_ELU);
+        K(lin_params(m->phi_x[2], S(g2, H), B, S(g3, H)), EPI_ELU);
+        gru(S(g3, H), 1);
+    }
+    return plan;
+}
+
+int run_forward(const bvc_model *m, const Workspace &w, const float *d_mel, const float *d_bits,
+                const uint8_t *h_use_gen, bool update_h, bool update_h2, const float *d_noise, int B, int64_t T,
+                float *d_dec, float *d_kld, float *d_z, float *d_prob, float *d_prior, hipStream_t s) {
+    const int H = m->cfg.h_dim, X = m->cfg.num_mels, Z = m->cfg.z_dim;
+    const long long BT = (long long)B * T;
+    int rc;
+    if (!m->has_prior) { set_error("bvc_bvrnn_forward: the model was created without the prior.* tensors"); return BVC_EMISSING; }
+    if (m->cfg.var_bit && !d_bits) { set_error("bits per frame required when var_bit=1"); return BVC_EINVAL; }
+    if (Z > H) { set_error("bvc_bvrnn_forward: z_dim > h_dim is not supported"); return BVC_EINVAL; }
+    // y = (y - mean) / std ; phi_x over all frames (bvrnn.py:96-101)
+    if ((rc = launch_normalize_rows(d_mel, m->mean_mel, m->std_mel, BT, X, w.yn, s))) return rc;
+    if ((rc = launch_gemm_batched(w.yn, X, m->phi_x[0].w, X, m->phi_x[0].b, (int)BT, H, X, 1, w.pxC, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxC, H, m->phi_x[1].w, H, m->phi_x[1].b, (int)BT, H, H, 1, w.pxB, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxB, H, m->phi_x[2].w, H, m->phi_x[2].b, (int)BT, H, H, 1, w.pxA, H, s, T))) return rc;
+    // h = h2 = 0 (bvrnn.py:103-104); both parities so that a state that is never updated stays zero
+    const long long MH = (long long)((B + 15) / 16) * 16 * H;
+    if ((rc = launch_fill(w.hbuf, 0.0f, 2 * MH, s))) return rc;
+    if ((rc = launch_fill(w.part_i, 0.0f, 2 * MH, s))) return rc;
+    // optional outputs fall back to workspace buffers that are idle during the recurrence (Z <= H, Z <= num_mels or not:
+    // pxB / pxC hold B*T*H floats each, mel B*T*num_mels)
+    float *prob = d_prob ? d_prob : w.pxB;
+    float *prior = d_prior ? d_prior : w.pxC;
+    float *z = d_z ? d_z : (Z <= X ? w.mel : w.pxB + BT * Z);
+    if (!d_z && Z > X && 2 * Z > H) { set_error("bvc_bvrnn_forward: pass d_z for this z_dim"); return BVC_EINVAL; }
+    CallDesc d;
+    memset(&d, 0, sizeof(d));
+    d.p[DS_PX] = w.pxA; d.p[DS_CODES] = z; d.p[DS_BITS] = const_cast<float *>(d_bits);
+    d.p[DS_PROB] = prob; d.p[DS_PRIOR] = prior; d.p[DS_MEL] = d_dec; d.p[DS_NOISE] = const_cast<float *>(d_noise);
+    d.T = T;
+    const bool greedy = d_noise == nullptr;
+    const std::vector<StepNode> plan0 = build_forward_step(m, w, B, 0, greedy, update_h, update_h2);
+    const std::vector<StepNode> plan1 = build_forward_step(m, w, B, 1, greedy, update_h, update_h2);
+    const bool kp = g_kprobe.enabled;                 // the in-kernel probes index by a fixed kernel count per step
+    g_kprobe.enabled = false;
+    rc = begin_call(m, w, d, count_kernels(plan0), s);
+    for (int64_t t = 0; !rc && t < T; ++t) rc = launch_steps(m, h_use_gen[t] ? plan1 : plan0, w, 1, s, nullptr);
+    g_kprobe.enabled = kp;
+    if (rc) return rc;
+    return launch_kld_frames(prob, prior, m->cfg.var_bit ? d_bits : nullptr, B, T, Z, d_kld, s);
+}
+
 // Runs the generator; stop_after: -1 = everything, otherwise the tap index of bvc_test_vocoder_tap.
 int run_vocoder(const bvc_model *m, const Workspace &w, const float *d_mel, int B, int64_t T, int64_t length,
                 float div, float *d_wav, int stop_after, const float **tap, int64_t *tap_len, int *tap_ch,
@@ -1040,6 +1165,23 @@ int bvc_bvrnn_decode(const bvc_model *m, const float *d_codes, const float *d_h0
     if (rc) return rc;
     if (!d_codes || !d_mel) { set_error("null argument"); return BVC_EINVAL; }
     return run_decode(m, w, d_ws, d_codes, d_h0, B, T, d_mel, d_hT, (hipStream_t)stream);
+}
+
+int bvc_bvrnn_forward(const bvc_model *m, const float *d_mel, const float *d_bits, const uint8_t *h_use_gen,
+                      int32_t update_h, int32_t update_h2, const float *d_noise, int32_t B, int64_t T, float *d_dec,
+                      float *d_kld, float *d_z, float *d_prob, float *d_prior, void *d_ws, size_t ws_bytes, void *stream) {
+    Workspace w;
+    int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
+    if (rc) return rc;
+    if (!d_mel || !h_use_gen || !d_dec || !d_kld) { set_error("null argument"); return BVC_EINVAL; }
+    if (!update_h && !update_h2) { set_error("bvc_bvrnn_forward: at least one state must be updated"); return BVC_EINVAL; }
+    for (int64_t t = 0; t < T; ++t)
+        if ((h_use_gen[t] && !update_h2) || (!h_use_gen[t] && !update_h)) {
+            set_error("bvc_bvrnn_forward: frame %lld is conditioned on a state that is never updated", (long long)t);
+            return BVC_EINVAL;
+        }
+    return run_forward(m, w, d_mel, d_bits, h_use_gen, update_h != 0, update_h2 != 0, d_noise, B, T, d_dec, d_kld, d_z,
+                       d_prob, d_prior, (hipStream_t)stream);
 }
 
 int bvc_bigvgan(const bvc_model *m, const float *d_mel, int32_t B, int64_t T, int64_t length, float out_scale_div,

@@ -250,9 +250,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             if (p.aux.base) o += p.aux.base[(long long)m * p.aux.ld + n];     // pre-computed half of a split dot product
             if (epi == EPI_ELU) o = elu1(o);
             store_out(y, m, n, o);
+        } else if (epi == EPI_SIGMOID) {
+            store_out(y, m, n, sigmoid1(v[0]));
         } else if (epi == EPI_CODE) {
             const float pr = sigmoid1(v[0]);
-            float z = rintf(pr);                                     // round half to even (torch.round)
+            float z;
+            if (p.sample == CS_ENCODE) {
+                z = rintf(pr);                                       // round half to even (torch.round)
+            } else {                                                 // BVRNN.forward: straight-through forward value
+                float arg = pr;
+                if (p.sample == CS_SAMPLE) {
+                    const Resolved un = resolve(p.y2, dsc, mt16, p.tstep);
+                    arg = __fadd_rn(__fsub_rn(un.p[(long long)m * un.ld + n], 0.5f), pr);     // (u - 0.5) + p
+                }
+                z = __fadd_rn(__fsub_rn(rintf(arg), pr), pr);        // round(.) - p + p
+            }
             if (p.var_bit) {
                 const Resolved bt = resolve(p.aux, dsc, mt16, p.tstep);
                 const float bits = bt.p[(long long)m * bt.ld];
@@ -561,6 +573,40 @@ int launch_copy_rows(const float *src, long long lds_, float *dst, long long ldd
     if (total <= 0) return BVC_OK;
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(copy_rows_kernel, dim3(grid), dim3(256), 0, s, src, lds_, dst, ldd, rows, n);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
+// ---- KL term of BVRNN.forward ---------------------------------------------------------------------
+// One workgroup per frame; thread (b, j) pairs strided, fixed-order tree reduction (deterministic).
+__global__ __launch_bounds__(256) void kld_frames_kernel(const float *__restrict__ prob, const float *__restrict__ prior,
+                                                         const float *__restrict__ bits, int B, long long T, int Z,
+                                                         float *__restrict__ kld) {
+    __shared__ float red[256];
+    const long long t = blockIdx.x;
+    float sum = 0.0f;
+    for (int i = threadIdx.x; i < B * Z; i += 256) {
+        const int b = i / Z, j = i - b * Z;
+        const long long o = ((long long)b * T + t) * Z + j;
+        if (bits && !(bits[(long long)b * T + t] > (float)j)) continue;        // kld_elem * bit_mask
+        const float e = prob[o], q = prior[o];
+        const float a = e * (logf(fmaxf(e, 1e-3f)) - logf(fmaxf(q, 1e-3f)));
+        const float c = (1.0f - e) * (logf(fmaxf(1.0f - e, 1e-3f)) - logf(fmaxf(1.0f - q, 1e-3f)));
+        sum += a + c;
+    }
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kld[t] = red[0] / (float)B;
+}
+
+int launch_kld_frames(const float *prob, const float *prior, const float *bits, int B, long long T, int Z, float *kld,
+                      hipStream_t s) {
+    if (T <= 0) return BVC_OK;
+    hipLaunchKernelGGL(kld_frames_kernel, dim3((unsigned)T), dim3(256), 0, s, prob, prior, bits, B, T, Z, kld);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }

@@ -176,6 +176,7 @@ struct AmpArgs {
     const float *w2, *b2, *a2, *ib2;
     float divisor;
     int epi, ks, dil, tiles_per_batch;
+    unsigned ntile;               // workgroups that have a tile (grid is padded to a multiple of 8)
     long long bs;                 // floats between batch items of x / out / acc
     long long row_begin;          // first output row (streaming: rows before it are history)
     long long t_origin;           // global time of buffer row 0 (streaming); 0 offline
@@ -203,8 +204,13 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
     const int r = lane & 15, g = lane >> 4;
     const int ks = a.ks, dil = a.dil;
     const int TT = TR - (ks - 1);                          // valid output rows of this workgroup
-    const int b = blockIdx.x / a.tiles_per_batch;
-    const long long t0 = a.row_begin + (long long)(blockIdx.x % a.tiles_per_batch) * TT;
+    // Workgroups are dealt round-robin to the 8 XCDs; neighbouring tiles share their halo rows, so each
+    // XCD takes a contiguous run of tiles (the halo then hits in that XCD's L2).
+    const unsigned nwg = gridDim.x, per = (nwg + 7u) >> 3;
+    unsigned bid = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (bid >= a.ntile) return;                           // grid is padded to a multiple of 8
+    const int b = bid / a.tiles_per_batch;
+    const long long t0 = a.row_begin + (long long)(bid % a.tiles_per_batch) * TT;
     const int halo1 = (ks - 1) * dil;
     const int rows1 = TR + halo1;                          // S1(x) rows [t0-(ks-1)-halo1, t0-(ks-1)+TR)
     float *t1 = lds;
@@ -408,7 +414,10 @@ static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
     const size_t lds = (size_t)((TR + (a.ks - 1) * a.dil) + TR + (a.ks - 1)) * (C + 2) * sizeof(float);
     if (lds > 160 * 1024 || TT <= 0) { set_error("amp_pair tile needs %zu B of LDS", lds); return BVC_EINVAL; }
     ProbeScope probe(PK_CONV, s);
-    hipLaunchKernelGGL((amp_pair_kernel<C, MT>), dim3((unsigned)(a.tiles_per_batch * (long long)B)), dim3(256), lds, s, a);
+    // grid rounded up to a multiple of 8 so that the XCD-contiguous renumbering covers every tile exactly once
+    const unsigned ntile = (unsigned)(a.tiles_per_batch * (long long)B);
+    a.ntile = ntile;
+    hipLaunchKernelGGL((amp_pair_kernel<C, MT>), dim3((ntile + 7u) & ~7u), dim3(256), lds, s, a);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }

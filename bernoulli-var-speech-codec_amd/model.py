@@ -144,6 +144,49 @@ class BVRNN(_OnDevice):
             self._engines = shared
 
     @torch.no_grad()
+    def forward(self, y, p_use_gen, greedy, varBitrate, *, r=None, noise=None, return_all=False):
+        """``BVRNN.forward(y, p_use_gen, greedy, varBitrate)`` (bvrnn.py:86-160), forward values only (this build
+        has no autograd): stochastic Bernoulli sampler ``round(u - 0.5 + enc_t)``, prior net, KL term and the
+        teacher-forcing mix.  Returns (all_dec_mean (B,T,x_dim), kld scalar) like the reference.
+
+        Randomness: the reference draws, per frame, ``torch.rand([])`` (compared with p_use_gen) and - unless
+        greedy - ``torch.rand_like(enc_t)``.  By default the same numbers are drawn here, in the same order, from
+        torch's global CPU generator, so ``torch.manual_seed(s)`` followed by this call reproduces the reference
+        run on CPU after the same seed.  ``r`` (T,) / ``noise`` (B,T,z_dim) override them.
+        ``return_all=True`` adds a dict with z (forward value of the sample), prob (enc_t), prior, kld_frames."""
+        eng = self.engine(y)
+        out_dev = y.device
+        y = _prep(y, eng.device)
+        B, T, _ = y.shape
+        if r is None or (noise is None and not greedy):
+            rs, ns = [], []
+            for _ in range(T):                                    # the reference's draw order (bvrnn.py:111,126)
+                rs.append(torch.rand([]))
+                if not greedy:
+                    ns.append(torch.rand(B, self.z_dim))
+            r = torch.stack(rs) if r is None else r
+            if not greedy and noise is None:
+                noise = torch.stack(ns, 1)
+        use_gen = (torch.as_tensor(r).detach().cpu().float() < p_use_gen).to(torch.uint8).contiguous()
+        assert use_gen.numel() == T
+        bits = _prep(varBitrate, eng.device) if (varBitrate is not None and self.varBit) else None
+        un = None if greedy else _prep(noise, eng.device)
+        dec = torch.empty(B, T, self.x_dim, device=eng.device)
+        kld = torch.empty(T, device=eng.device)
+        extra = {k: torch.empty(B, T, self.z_dim, device=eng.device) for k in ("z", "prob", "prior")} if return_all else {}
+        ws, nws = eng.workspace(B, T)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.lib.bvc_bvrnn_forward(
+                eng.handle, _abi.ptr(y), _abi.ptr(bits), ctypes.c_void_p(use_gen.data_ptr()), int(p_use_gen < 1),
+                int(p_use_gen > 0), _abi.ptr(un), B, T, _abi.ptr(dec), _abi.ptr(kld), _abi.ptr(extra.get("z")),
+                _abi.ptr(extra.get("prob")), _abi.ptr(extra.get("prior")), ws, nws, eng.stream()))
+        out = (dec.to(out_dev), torch.mean(kld).to(out_dev))     # torch.mean(torch.stack(kld_loss)), bvrnn.py:160
+        if return_all:
+            extra["kld_frames"] = kld
+            return out + ({k: v.to(out_dev) for k, v in extra.items()},)
+        return out
+
+    @torch.no_grad()
     def encode(self, y, varBitrate, h, return_prob=False):
         """y (B,T,x_dim), varBitrate (B,T) bits/frame, h (1,B,h_dim) -> (codes (B,T,z), all_h (B,T,h))."""
         eng = self.engine(y)

@@ -70,7 +70,7 @@ def host_tensors(conf, vrnn_sd, gen_sd):
     _strict(gen_sd, expected_generator_keys(conf), "BigVGAN")
     out = {}
     for k, t in vrnn_sd.items():
-        if k.startswith("prior.") or k == "log_sigma":      # training-only (bvrnn.py:68-73,33)
+        if k == "log_sigma":                                # only used by the training loss (bvrnn.py:33)
             continue
         out[k] = t
     for k, t in gen_sd.items():

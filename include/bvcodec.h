@@ -109,6 +109,22 @@ int bvc_bvrnn_decode(const bvc_model *m, const float *d_codes, const float *d_h0
                      int64_t T, float *d_mel, float *d_hT, void *d_ws, size_t ws_bytes,
                      void *stream);
 
+/* BVRNN.forward (bvrnn.py:86-160), forward VALUES only (no autograd): the training-time pass with the
+ * stochastic Bernoulli sampler round(u - 0.5 + p), the prior net and the KL term.
+ *   d_mel (B,T,num_mels), d_bits (B,T) (NULL unless var_bit);
+ *   h_use_gen: HOST array of T bytes, use_gen[t] = (random_num_t < p_use_gen), bvrnn.py:111-120: frame t is
+ *     conditioned on h2 (the state fed with generated features) when set, else on h (teacher-forced);
+ *   update_h = (p_use_gen < 1), update_h2 = (p_use_gen > 0)  (bvrnn.py:142-145);
+ *   d_noise (B,T,z_dim) uniform [0,1) samples, or NULL for greedy=True (bvrnn.py:123-126);
+ *   outputs: d_dec (B,T,num_mels) = all_dec_mean, d_kld (T) = per-frame KLD terms (the reference returns their
+ *   mean, bvrnn.py:160); optional d_z (forward value of z_t, i.e. round(.) - p + p, masked), d_prob (enc_t),
+ *   d_prior (prior_t), each (B,T,z_dim).  Needs the prior.{0,2,4}.{weight,bias} tensors at bvc_model_create. */
+int bvc_bvrnn_forward(const bvc_model *m, const float *d_mel, const float *d_bits,
+                      const uint8_t *h_use_gen, int32_t update_h, int32_t update_h2,
+                      const float *d_noise, int32_t B, int64_t T, float *d_dec, float *d_kld,
+                      float *d_z, float *d_prob, float *d_prior, void *d_ws, size_t ws_bytes,
+                      void *stream);
+
 /* BigVGAN.forward(x, length) (models.py:207-238) followed by `/ out_scale_div`
  * (bvrnn_codec_model.py:71: .squeeze(1) / SCALING).  d_mel is TIME-major (B,T,num_mels), i.e. what
  * bvc_bvrnn_decode emits (the reference permutes to (B,80,T) first).  d_wav (B, n_out) with

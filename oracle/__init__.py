@@ -21,7 +21,8 @@ algorithm for the path (citations are relative to the reference checkout):
                      librosa itself.
 * ``frontend.py``  - ``mel_spectrogram``  (``meldataset.py:60-95``, ``:38-39``).
 * ``bvrnn.py``     - ``BVRNN.encode`` / ``BVRNN.decode`` (``bvrnn.py:163-229``, nets
-                     ``bvrnn.py:44-83``), GRU cell equations of ``torch.nn.GRU``.
+                     ``bvrnn.py:44-83``), GRU cell equations of ``torch.nn.GRU``; ``BVRNN.forward``
+                     (``bvrnn.py:86-160``: sampler, prior, KLD) with the random numbers as inputs.
 * ``bigvgan.py``   - ``BigVGAN.forward`` (``third_party/BigVGAN/models.py:207-238``),
                      ``AMPBlock1.forward`` (``models.py:103-121``), ``SnakeBeta``
                      (``third_party/BigVGAN/activations.py:107-120``), weight-norm fold.
@@ -29,7 +30,7 @@ algorithm for the path (citations are relative to the reference checkout):
                      (``bvrnn_codec_model.py:44-76``).
 
 How it is pinned: ``tests/golden/*.npz`` were produced by importing the reference itself
-in the build container (``tests/golden/make_golden.py``, committed) on seeded synthetic
+in the build container (``tests/golden/make_golden.py`` and ``make_golden_forward.py``, committed) on seeded synthetic
 checkpoints; ``tests/test_oracle_golden.py`` checks every oracle stage against them.
 The reference has no tests, golden vectors or known-answer fixtures of its own
 (SURVEY.md section 4), and its trained checkpoints are Git-LFS pointers.

@@ -101,3 +101,70 @@ def decode(sd, z, h0, dtype=torch.float32):
         pxg = phi_x(sd, (d - mean[None, :]) / std[None, :])
         h = gru_cell(sd, torch.cat([pxg, pz], 1), h)
     return dict(mel=torch.stack(out).permute(1, 0, 2).contiguous(), h_last=h)
+
+
+def prior_prob(sd, h):     # bvrnn.py:68-73 (with the final Sigmoid)
+    return torch.sigmoid(_mlp(sd, "prior", (0, 2, 4), h, last_act=False))
+
+
+def draw_randomness(T, B, zdim, greedy, generator=None):
+    """The random numbers ``BVRNN.forward`` consumes, in its order (bvrnn.py:111,129): per frame one scalar
+    ``torch.rand([])`` and, unless greedy, one ``torch.rand_like(enc_t)`` of shape (B, z_dim).  Drawn from
+    the given (default: global CPU) generator.  Returns (r (T,), noise (B,T,Z) or None)."""
+    r, noise = [], []
+    for _ in range(T):
+        r.append(torch.rand([], generator=generator))
+        if not greedy:
+            noise.append(torch.rand(B, zdim, generator=generator))
+    return torch.stack(r), (None if greedy else torch.stack(noise, 1).contiguous())
+
+
+@torch.no_grad()
+def forward(sd, y, p_use_gen, greedy, bits_per_frame, r, noise, var_bit=True, dtype=torch.float32):
+    """``BVRNN.forward`` (bvrnn.py:86-160), forward values only.  r (T,) are the per-frame scalars compared
+    against p_use_gen, noise (B,T,Z) the uniform samples of the Bernoulli sampler (None when greedy).
+
+    Returns dict(dec (B,T,80), kld scalar, kld_frames (T,), z (B,T,Z) [forward value of the straight-through
+    sample], prob (B,T,Z) [enc_t], prior (B,T,Z), arg (B,T,Z) [the value that is rounded])."""
+    sd = cast_state(sd, dtype)
+    y = torch.as_tensor(y).to(dtype)
+    mean, std = sd["mean_mel"], sd["std_mel"]
+    yn = (y - mean[None, None, :]) / std[None, None, :]              # bvrnn.py:96
+    px = phi_x(sd, yn)                                               # bvrnn.py:101
+    B, T = y.shape[:2]
+    H = sd["rnn.weight_hh_l0"].shape[1]
+    zdim = sd["enc.4.weight"].shape[0]
+    h = torch.zeros(B, H, dtype=dtype)                               # bvrnn.py:103-104
+    h2 = torch.zeros(B, H, dtype=dtype)
+    if var_bit:                                                      # bvrnn.py:105-107
+        bits = torch.as_tensor(bits_per_frame).to(dtype)
+        mask = (bits[:, :, None] > torch.arange(zdim, dtype=dtype)[None, None, :]).to(dtype)
+    outs = dict(dec=[], z=[], prob=[], prior=[], arg=[])
+    kld = []
+    for t in range(T):                                               # bvrnn.py:110
+        hs = h2 if bool(r[t] < p_use_gen) else h                     # bvrnn.py:115-120
+        e = torch.sigmoid(enc_logits(sd, torch.cat([px[:, t], hs], 1)))
+        pr = prior_prob(sd, hs)
+        if greedy:                                                   # bvrnn.py:123-126 (straight-through value)
+            arg = e
+        else:
+            arg = torch.as_tensor(noise[:, t]).to(dtype) - 0.5 + e
+        z = torch.round(arg) - e + e
+        if var_bit:                                                  # bvrnn.py:128-129
+            z = z * mask[:, t] + 0.5 * (1 - mask[:, t])
+        pz = phi_z(sd, z)                                            # bvrnn.py:131
+        d = dec(sd, torch.cat([pz, hs], 1))                          # bvrnn.py:134-137
+        pxg = phi_x(sd, (d - mean[None, :]) / std[None, :])          # bvrnn.py:139
+        if p_use_gen < 1:                                            # bvrnn.py:142-145
+            h = gru_cell(sd, torch.cat([px[:, t], pz], 1), h)
+        if p_use_gen > 0:
+            h2 = gru_cell(sd, torch.cat([pxg, pz], 1), h2)
+        ke = e * (torch.log(torch.clip(e, 1e-3)) - torch.log(torch.clip(pr, 1e-3))) + \
+            (1 - e) * (torch.log(torch.clip(1 - e, 1e-3)) - torch.log(torch.clip(1 - pr, 1e-3)))   # bvrnn.py:148-149
+        kld.append(torch.mean(torch.sum(ke * mask[:, t], -1)) if var_bit else torch.mean(torch.sum(ke, -1)))
+        for k, v in (("dec", d), ("z", z), ("prob", e), ("prior", pr), ("arg", arg)):
+            outs[k].append(v)
+    res = {k: torch.stack(v).permute(1, 0, 2).contiguous() for k, v in outs.items()}
+    res["kld_frames"] = torch.stack(kld)
+    res["kld"] = torch.mean(res["kld_frames"])                       # bvrnn.py:160
+    return res

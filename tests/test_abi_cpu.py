@@ -90,7 +90,7 @@ def test_weight_norm_fold_matches_oracle(conf_var):
     for name in ("conv_pre", "ups.1.1", "resblocks.4.convs1.2", "conv_post"):
         ref = obig.fold_weight_norm(g[name + ".weight_g"], g[name + ".weight_v"])
         assert torch.equal(ht[name + ".weight"], ref) or (ht[name + ".weight"] - ref).abs().max() < 1e-7
-    assert "prior.0.weight" not in ht and "log_sigma" not in ht
+    assert "prior.0.weight" in ht and "log_sigma" not in ht       # prior net: bvc_bvrnn_forward; log_sigma: loss only
     assert ht["mel_basis"].shape == (80, 513) and ht["hann_window"].shape == (1024,)
     assert all(t.dtype == torch.float32 and t.is_contiguous() for t in ht.values())
 

@@ -125,6 +125,64 @@ def test_bvrnn_vs_reference_golden(tag, h_dim, var_bit):
     assert np.abs(hT[0].cpu().numpy() - g["h_T"]).max() < 5e-6
 
 
+@pytest.mark.parametrize("tag,h_dim,var_bit", [("h1024_var", 1024, True), ("h1024_fix", 1024, False),
+                                              ("h64_var", 64, True)])
+def test_bvrnn_forward_vs_reference_golden(tag, h_dim, var_bit):
+    """bvc_bvrnn_forward == the reference's BVRNN.forward (bvrnn.py:86-160) on the recorded random numbers:
+    greedy / sampled, p_use_gen in {0, 0.5, 1}."""
+    from gpu_common import make_model
+    model = make_model(var_bit, h_dim)[0]
+    g = load_golden(f"g8_bvrnn_forward_{tag}")
+    for mode in range(4):
+        k = f"m{mode}_"
+        greedy = bool(g[k + "greedy"])
+        noise = None if greedy else t(g[k + "noise"])
+        dec, kld, ex = model.bvrnn(t(g[k + "y"]).to(DEV), float(g[k + "p_use_gen"]), greedy, t(g[k + "bits"]).to(DEV),
+                                   r=t(g[k + "r"]), noise=noise, return_all=True)
+        assert np.abs(ex["prob"].cpu().numpy() - g[k + "prob"]).max() < 3e-6, mode
+        assert np.abs(ex["prior"].cpu().numpy() - g[k + "prior"]).max() < 3e-6, mode
+        assert np.abs(dec.cpu().numpy() - g[k + "dec"]).max() < 5e-5, mode
+        assert abs(float(kld) - float(g[k + "kld"])) < 2e-6 * max(1.0, abs(float(g[k + "kld"]))), mode
+    # default randomness: same numbers as the reference draws after the same torch seed (global CPU generator)
+    torch.manual_seed(int(g["m2_torch_seed"]))
+    dec2, kld2 = model.bvrnn(t(g["m2_y"]).to(DEV), float(g["m2_p_use_gen"]), False, t(g["m2_bits"]).to(DEV))
+    assert np.abs(dec2.cpu().numpy() - g["m2_dec"]).max() < 5e-5
+    assert abs(float(kld2) - float(g["m2_kld"])) < 2e-6
+
+
+def test_bvrnn_forward_vs_oracle_larger(env):
+    """B=20 (ragged row tile), T=40, sampled with mixed teacher forcing: sample bits equal the oracle's except at
+    ties of the rounding, decoder output and KLD agree."""
+    from oracle import bvrnn as obv
+    model, conf, vr, _ = env
+    rng = np.random.default_rng(9)
+    B, T = 20, 40
+    y = torch.from_numpy((-4.0 + 1.6 * rng.standard_normal((B, T, 80))).astype(np.float32))
+    bits = torch.from_numpy(rng.integers(0, 65, size=(B, T)).astype(np.float32))
+    gen = torch.Generator().manual_seed(77)
+    r, noise = obv.draw_randomness(T, B, 64, False, generator=gen)
+    o = obv.forward(vr, y, 0.3, False, bits, r, noise)
+    dec, kld, ex = model.bvrnn(y.to(DEV), 0.3, False, bits.to(DEV), r=r, noise=noise, return_all=True)
+    z, zo = ex["z"].cpu(), o["z"]
+    diff = (z - zo).abs() > 0.25
+    first_bad = T
+    for b in range(B):
+        if diff[b].any():
+            t0 = int(diff[b].any(dim=1).nonzero()[0])
+            bad = diff[b, t0].nonzero().flatten()
+            assert ((o["arg"][b, t0, bad] - 0.5).abs() < 1e-5).all(), (b, t0)     # only ties may flip
+            first_bad = min(first_bad, t0)
+    # frames before the first flipped tie (normally: all of them) agree closely
+    assert first_bad > 0
+    assert (dec.cpu()[:, :first_bad] - o["dec"][:, :first_bad]).abs().max() < 1e-4
+    assert (ex["kld_frames"].cpu()[:first_bad] - o["kld_frames"][:first_bad]).abs().max() < 1e-5
+    if first_bad == T:
+        assert abs(float(kld) - float(o["kld"])) < 1e-5
+    # argument checking: a frame conditioned on a state that is never updated is rejected
+    with pytest.raises(RuntimeError):
+        model.bvrnn(y.to(DEV), 0.0, True, bits.to(DEV), r=torch.full((T,), -1.0))
+
+
 def test_bvrnn_free_running_vs_oracle(env):
     """Larger free-running case: any differing bit must be a tie of the reference arithmetic
     (|p-0.5| < 1e-5 in the oracle) at the FIRST differing frame of that utterance."""

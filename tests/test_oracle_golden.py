@@ -76,6 +76,33 @@ def test_bvrnn_matches_reference(tag, h_dim, var_bit, conf_var):
     assert np.array_equal(r2["codes"].numpy(), g["codes"])
 
 
+@pytest.mark.parametrize("tag,h_dim,var_bit", [("h1024_var", 1024, True), ("h1024_fix", 1024, False),
+                                              ("h64_var", 64, True)])
+def test_bvrnn_forward_matches_reference(tag, h_dim, var_bit, conf_var):
+    """BVRNN.forward (bvrnn.py:86-160): sampler, prior, KLD, teacher-forcing mix - fixtures made by
+    tests/golden/make_golden_forward.py from the reference with the recorded random numbers."""
+    g = load_golden(f"g8_bvrnn_forward_{tag}")
+    c = dict(conf_var); c["h_dim"] = h_dim; c["var_bit"] = var_bit
+    sd = synth.bvrnn_state_dict(c, seed=int(g["seed"]))
+    for mode in range(4):
+        k = f"m{mode}_"
+        greedy = bool(g[k + "greedy"])
+        noise = None if greedy else t(g[k + "noise"])
+        r = obv.forward(sd, t(g[k + "y"]), float(g[k + "p_use_gen"]), greedy, t(g[k + "bits"]), t(g[k + "r"]), noise,
+                        var_bit=var_bit)
+        assert np.abs(r["prob"].numpy() - g[k + "prob"]).max() < 2e-6, mode
+        assert np.abs(r["prior"].numpy() - g[k + "prior"]).max() < 2e-6, mode
+        assert np.abs(r["dec"].numpy() - g[k + "dec"]).max() < 2e-5, mode
+        assert abs(float(r["kld"]) - float(g[k + "kld"])) < 1e-6 * max(1.0, abs(float(g[k + "kld"]))), mode
+        # the sample takes the straight-through forward value round(.) - p + p: within 1 ulp of {0, 1} (0.5 when masked)
+        z = r["z"].numpy()
+        assert np.abs(z - np.round(z * 2) / 2).max() < 2e-7
+    # the stored random numbers are what torch's CPU generator yields after the recorded seed, in the reference's order
+    torch.manual_seed(int(g["m2_torch_seed"]))
+    rr, nn_ = obv.draw_randomness(g["m2_y"].shape[1], g["m2_y"].shape[0], 64, False)
+    assert np.array_equal(rr.numpy(), g["m2_r"]) and np.array_equal(nn_.numpy(), g["m2_noise"])
+
+
 def test_bvrnn_float64_truth_agrees_on_codes(conf_var):
     g = load_golden("g3_bvrnn_h1024_var")
     sd = synth.bvrnn_state_dict(conf_var, seed=int(g["seed"]))
