@@ -20,6 +20,7 @@
 //      out[q*u + p, co] = b[co] + sum_ci in[q, ci] W[ci, co, p] + in[q-1, ci] W[ci, co, p+u]
 // is a 2-tap causal convolution with u*Cout output columns whose (B, Lin+1, u*Cout) result IS the
 // (B, (Lin+1)*u, Cout) channels-last signal.
+#include <cstdlib>
 #include <type_traits>
 
 #include "bvc_internal.h"
@@ -40,21 +41,22 @@ struct ConvArgs {
     int epi, ks, dil, cout, ntiles, tiles_per_batch;
 };
 
-// sin(x)^2 with |error| < 1.7e-7 for |x| < 2000 (three-constant Cody-Waite reduction by pi/2 with
-// fma, cephes minimax polynomials on [-pi/4, pi/4]; the square removes the quadrant sign).  ocml's
-// sinf is equally accurate but carries a Payne-Hanek path and costs ~3x the instructions; the
-// generator evaluates 476 of these per output sample.
+// sin(x)^2 with |error| < 1.7e-7 for |x| < 2000: three-constant Cody-Waite reduction by pi/2 with fma to
+// r in [-pi/4, pi/4], then ONE even minimax polynomial sin(r)^2 = u*P(u), u = r^2 (|P error| < 5e-10), and
+// sin(x)^2 = sin(r)^2 in even quadrants, 1 - sin(r)^2 (= cos(r)^2) in odd ones: the square removes the
+// quadrant sign, so no second polynomial is needed.  16 VALU operations; ocml's sinf is equally accurate
+// but carries a Payne-Hanek path and costs ~4x the instructions, and the generator evaluates 476 of these
+// per output sample on SIMDs whose issue slots it shares with the MFMAs.
 __device__ __forceinline__ float sin_squared(float x) {
     const float k = rintf(x * 0.636619772367581343f);
     float r = fmaf(-k, 1.57079625129699707031e+00f, x);
     r = fmaf(-k, 7.54978941586159635335e-08f, r);
     r = fmaf(-k, 5.39030252995776476554e-15f, r);
-    const float r2 = r * r;
-    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
-    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f),
-                          r2 * r2, fmaf(-0.5f, r2, 1.0f));
-    const float v = (((int)k) & 1) ? cp : sp;
-    return v * v;
+    const float u = r * r;
+    const float p = fmaf(fmaf(fmaf(fmaf(1.345194032182917e-4f, u, -3.1710113398730755e-3f), u, 4.444364085793495e-2f), u,
+                              -3.33333283662796e-1f), u, 1.0f);
+    const float s2 = p * u;
+    return (((int)k) & 1) ? 1.0f - s2 : s2;
 }
 
 // SnakeBeta (activations.py:107-120): x + 1/(exp(beta)+1e-9) * sin(x*exp(alpha))^2
@@ -188,8 +190,8 @@ __device__ unsigned long long g_phase[16];
 #else
 #define PHASE(i)
 #endif
-template <int C, int MT>
-__global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArgs a) {
+template <int C, int MT, int OCC, bool ALIAS>
+__global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
 #ifdef BVC_PHASE_PROBE
     unsigned long long last_ = __builtin_readcyclecounter();
 #endif
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
     constexpr int NT = (C + 15) / 16;
     constexpr int C4 = C / 4;
     constexpr int TR = 4 * MT * 16;                       // rows computed by each conv phase
-    constexpr int CGU = (C4 % 8 == 0) ? 8 : (C4 % 4 == 0) ? 4 : 2;
+    constexpr int CGU = (C >= 64) ? 4 : (C4 % 8 == 0) ? 8 : (C4 % 4 == 0) ? 4 : 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
     const int halo1 = (ks - 1) * dil;
     const int rows1 = TR + halo1;                          // S1(x) rows [t0-(ks-1)-halo1, t0-(ks-1)+TR)
     float *t1 = lds;
-    float *t2 = lds + rows1 * S;                           // S2(u) rows [t0-(ks-1), t0-(ks-1)+TR) (+ ks-1 spare)
+    float *t2 = ALIAS ? lds : lds + rows1 * S;             // S2(u) rows [t0-(ks-1), t0-(ks-1)+TR) (+ ks-1 spare): takes over
+                                                           // the S1(x) tile once conv1 has consumed it (halves the LDS)
     const float *xb = a.x + (long long)b * a.bs;
     const long long tbase = t0 - (ks - 1);                 // global row of local row 0 of phase 2 / t2
 
@@ -248,7 +251,6 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
             }
         }
     }
-    for (int idx = tid; idx < (ks - 1) * S; idx += 256) t2[TR * S + idx] = 0.0f;    // spare rows read by discarded outputs
     __syncthreads();
     PHASE(0);
 
@@ -271,10 +273,8 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
 #pragma unroll
                 for (int n = 0; n < NT; ++n) dstb[u][n] = wq[(u * NT + n) * 64];
         };
-        loadb(bcur, 0);
-#pragma unroll 1
-        for (int q = 0; q < nch; ++q) {
-            if (q + 1 < nch) loadb(bnxt, q + 1);
+        // two register sets take turns (no copies): chunk q+1 is in flight while chunk q feeds the MFMAs
+        auto compute = [&](const float (&bw)[CGU][NT], int q) {
             const int j = q / CPT, cg0 = (q - j * CPT) * CGU;
             const float *arow = tile + (mbase + r + j * d) * S + g;
 #pragma unroll
@@ -286,8 +286,19 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bcur[u][n], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bw[u][n], acc[i][n], 0, 0, 0);
             }
+        };
+        // The prefetch is UNCONDITIONAL (past the end it re-reads the last chunk): a load under a branch makes
+        // the compiler wait with vmcnt(0) before the next MFMA, i.e. for the prefetch it has just issued, or
+        // sink the load next to its use.  The register copy at the end of a chunk is where the wait belongs.
+        loadb(bcur, 0);
+#pragma unroll 1
+        for (int q = 0; q < nch; ++q) {
+            loadb(bnxt, q + 1 < nch ? q + 1 : nch - 1);
+            __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this chunk's MFMAs
+            compute(bcur, q);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < CGU; ++u)
 #pragma unroll
@@ -335,6 +346,8 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
     // ---- phase 2: u = conv1(S1(x)) ; t2 = S2(u + b1), zero before the start of the signal
     conv(t1, dil, a.w1);
     PHASE(1);
+    if (ALIAS) __syncthreads();                            // every wave is done with S1(x): its LDS becomes t2
+    for (int idx = tid; idx < (ks - 1) * S; idx += 256) t2[TR * S + idx] = 0.0f;    // spare rows read by discarded outputs
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int col = n * 16 + r;
@@ -374,6 +387,7 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
     PHASE(3);
     conv(t2, 1, a.w2);
     PHASE(4);
+    if (ALIAS) __syncthreads();                            // t2 is dead: the same LDS now stages the output tile
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int col = n * 16 + r;
@@ -405,19 +419,23 @@ __global__ __launch_bounds__(256, (C <= 32 ? 4 : 2)) void amp_pair_kernel(AmpArg
     PHASE(5);
 }
 
-template <int C, int MT>
+template <int C, int MT, int OCC, bool ALIAS>
 static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
     constexpr int TR = 4 * MT * 16;
     const int TT = TR - (a.ks - 1);
     a.tiles_per_batch = (int)((a.L - a.row_begin + TT - 1) / TT);
     if (a.tiles_per_batch <= 0) return BVC_OK;
-    const size_t lds = (size_t)((TR + (a.ks - 1) * a.dil) + TR + (a.ks - 1)) * (C + 2) * sizeof(float);
+    const size_t lds = (size_t)((TR + (a.ks - 1) * a.dil) + (ALIAS ? 0 : TR + (a.ks - 1))) * (C + 2) * sizeof(float);
     if (lds > 160 * 1024 || TT <= 0) { set_error("amp_pair tile needs %zu B of LDS", lds); return BVC_EINVAL; }
     ProbeScope probe(PK_CONV, s);
     // grid rounded up to a multiple of 8 so that the XCD-contiguous renumbering covers every tile exactly once
     const unsigned ntile = (unsigned)(a.tiles_per_batch * (long long)B);
     a.ntile = ntile;
-    hipLaunchKernelGGL((amp_pair_kernel<C, MT>), dim3((ntile + 7u) & ~7u), dim3(256), lds, s, a);
+    {
+        static bool attr = false;
+        if (!attr) { BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<C, MT, OCC, ALIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    }
+    hipLaunchKernelGGL((amp_pair_kernel<C, MT, OCC, ALIAS>), dim3((ntile + 7u) & ~7u), dim3(256), lds, s, a);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }
@@ -438,10 +456,12 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
     a.row_begin = win ? win->row_begin : 0;
     a.t_origin = win ? win->t_origin : 0;
     switch (c1.cin) {
-        case 64: return launch_amp_t<64, 1>(a, B, s);
-        case 32: return launch_amp_t<32, 2>(a, B, s);
-        case 16: return launch_amp_t<16, 2>(a, B, s);
-        case 8:  return launch_amp_t<8, 2>(a, B, s);
+        // tile shapes from a measured sweep (tools/voc_stage_times.py): MT = 16-row tiles per wave, OCC = workgroups per CU the
+        // register budget is set for, ALIAS = the S2 tile re-uses the LDS of the S1 tile (one more barrier, half the LDS)
+        case 64: return launch_amp_t<64, 2, 2, true>(a, B, s);      // 3.12 -> 2.62 ms per step vs <64,1,2,false>
+        case 32: return launch_amp_t<32, 4, 3, true>(a, B, s);      // 4.96 -> 4.83
+        case 16: return launch_amp_t<16, 2, 4, false>(a, B, s);     // (MT 4 / ALIAS: no gain)
+        case 8:  return launch_amp_t<8, 4, 4, true>(a, B, s);       // 3.14 -> 2.74
         default: set_error("amp_pair: unsupported channel count %d", c1.cin); return BVC_EINVAL;
     }
 }
@@ -473,10 +493,6 @@ static int allow_big_lds() {
 
 int conv_kernels_init() {
     int rc;
-    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     if ((rc = allow_big_lds<128, 4, 2>())) return rc;
     if ((rc = allow_big_lds<80, 4, 2>())) return rc;
     if ((rc = allow_big_lds<64, 4, 2>())) return rc;
