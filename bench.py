@@ -252,7 +252,7 @@ def main():
                            "kernel": r["kernel"], "mean_launch_us": r["mean_us"],
                            "launches_per_step": r["launches_per_step"],
                            "timer": r["timer"],
-                           "rocprof_avg_us": "5.2 (rocprofv3 --kernel-trace, dispatch-inclusive, --streams 1: profiles/r01_h_kernel_stats_final_1stream.csv)",
+                           "rocprof_avg_us": "5.0 (rocprofv3 --kernel-trace, dispatch-inclusive, --streams 1: profiles/r01_l_kernel_stats_final_1stream.csv)",
                            "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32); algorithmic FLOPs per launch / "
                                    "launch duration measured in situ inside the real schedule"}
         out["kernel_families"] = rows
