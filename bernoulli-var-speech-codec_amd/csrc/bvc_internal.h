@@ -125,11 +125,12 @@ int skinny_kernels_init();
 int launch_step_advance(CallDesc *d, int by, hipStream_t s);
 int launch_set_desc(CallDesc *d, const CallDesc &v, hipStream_t s);
 
-// batched GEMM over all frames: y = act(x @ w^T + bias), M large
-// frames_T > 0: rows are (b, t) pairs, b = row / frames_T, and y is written frame-packed:
-// frame t holds the fragment-packed [B][N] matrix at y + t * ceil(B/16)*16 * N.
+// batched GEMM over all frames: y = act(x @ w^T + bias), M large.  out_mode (GemmOut) says where the rows go:
+// see out_index() in k_gemm.hip.  frames_T = frames per utterance, mt16 = utterances rounded up to 16.
+enum GemmOut { GO_NATURAL = 0, GO_FRAME_MAJOR_ROWS = 1, GO_PACKED_FRAMES = 2, GO_PACKED_FROM_UTT = 3 };
 int launch_gemm_batched(const float *x, long long ldx, const float *w, long long ldw, const float *bias,
-                        int M, int N, int K, int act, float *y, long long ldy, hipStream_t s, long long frames_T = 0);
+                        int M, int N, int K, int act, float *y, long long ldy, hipStream_t s,
+                        int out_mode = GO_NATURAL, long long frames_T = 0, int mt16 = 0);
 // yn = (y - mean) / std over rows of length n (bvrnn.py:173)
 int launch_normalize_rows(const float *y, const float *mean, const float *stdv, long long rows, int n,
                           float *out, hipStream_t s);

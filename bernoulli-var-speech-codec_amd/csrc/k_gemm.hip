@@ -406,6 +406,27 @@ int launch_set_desc(CallDesc *d, const CallDesc &v, hipStream_t s) {
     return BVC_OK;
 }
 
+// Where element (row, col) of a batched GEMM goes (GemmOut):
+//   GO_NATURAL           y[row][col]
+//   GO_FRAME_MAJOR_ROWS  rows come utterance-major (row = b*T + t) and leave frame-major (row' = t*mt16 + b):
+//                        the following layers then see whole 16-utterance groups of ONE frame per row tile
+//   GO_PACKED_FRAMES     rows are frame-major (row = t*mt16 + b); frame t is written as the fragment-packed
+//                        [mt16][N] matrix the recurrent kernels read: a 16x16 MFMA tile is one 1 KiB block
+//   GO_PACKED_FROM_UTT   utterance-major rows straight to packed frames (16-byte granules; small jobs only)
+__device__ __forceinline__ long long out_index(int row, int col, int N, long long ldy, long long T, int mt16, int mode) {
+    if (mode == GO_NATURAL) return (long long)row * ldy + col;
+    if (mode == GO_FRAME_MAJOR_ROWS) {
+        const long long bb = row / T, tt = row - bb * T;
+        return (tt * mt16 + bb) * ldy + col;
+    }
+    if (mode == GO_PACKED_FRAMES) {
+        const int tt = row / mt16, bb = row - tt * mt16;
+        return (long long)tt * mt16 * N + packed_off(bb, col, N);
+    }
+    const long long bb = row / T, tt = row - bb * T;
+    return tt * (long long)mt16 * N + packed_off((int)bb, col, N);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Batched GEMM: y[M,N] = act(x[M,K] @ w[N,K]^T + bias).  128x128 per workgroup, 64x64 per wave.
 template <int ACT>
@@ -413,7 +434,7 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
                                                            const float *__restrict__ w, long long ldw,
                                                            const float *__restrict__ bias, int M, int N,
                                                            int K, float *__restrict__ y, long long ldy,
-                                                           long long frames_T, int mt16) {
+                                                           long long frames_T, int mt16, int out_mode) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -468,35 +489,148 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
                 if (row < M) {
                     float v = acc[i][j][e] + b;
                     if (ACT == 1) v = elu1(v);
-                    if (frames_T > 0) {                          // row = b * T + t -> packed [B][N] matrix of frame t
-                        const long long bb = row / frames_T, tt = row - bb * frames_T;
-                        y[tt * (long long)mt16 * N + packed_off((int)bb, col, N)] = v;
-                    } else {
-                        y[(long long)row * ldy + col] = v;
-                    }
+                    y[out_index(row, col, N, ldy, frames_T, mt16, out_mode)] = v;
+                }
+            }
+    }
+}
+
+// LDS-tiled variant for the large layers (K a multiple of 32, N a multiple of 128): 128x128 tile, 32-deep
+// stages, two LDS buffers.  The next stage travels global -> registers while the current one feeds the
+// MFMAs, and is parked in the other LDS buffer afterwards (one barrier per stage).  Rows are padded to
+// 36 floats so that the 16-byte fragment reads of 8 consecutive lanes cover all banks.  The k order seen
+// by each accumulator is the one of gemm_batched_kernel (16-blocks in order, k = 4*g + e inside), so both
+// produce the same bits.
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_batched_lds_kernel(const float *__restrict__ x, long long ldx,
+                                                                  const float *__restrict__ w, long long ldw,
+                                                                  const float *__restrict__ bias, int M, int N,
+                                                                  int K, float *__restrict__ y, long long ldy,
+                                                                  long long frames_T, int mt16, int out_mode) {
+    constexpr int BK = 32, LDT = BK + 4;                 // floats per LDS row
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A 128xLDT | B 128xLDT]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int mblk = blockIdx.y * 128, nblk = blockIdx.x * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    // global staging: thread -> (row = tid/8 + 32*p, 16-byte piece tid%8) of the 128 x 32 stage of each operand
+    const int srow = tid >> 3, spc = (tid & 7) * 4;
+    const float *xg[4], *wg[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = mblk + srow + 32 * p;
+        xg[p] = x + (long long)(row < M ? row : M - 1) * ldx + spc;      // rows past M: re-read the last one, never stored
+        wg[p] = w + (long long)(nblk + srow + 32 * p) * ldw + spc;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ga[4], gb[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ga[p] = *reinterpret_cast<const f32x4 *>(xg[p] + (long long)kt * BK);
+            gb[p] = *reinterpret_cast<const f32x4 *>(wg[p] + (long long)kt * BK);
+        }
+    };
+    auto park = [&](int buf) {
+        float *A = smem + buf * (2 * 128 * LDT), *B = A + 128 * LDT;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<f32x4 *>(A + (srow + 32 * p) * LDT + spc) = ga[p];
+            *reinterpret_cast<f32x4 *>(B + (srow + 32 * p) * LDT + spc) = gb[p];
+        }
+    };
+    const int nk = K / BK;
+    gload(0);
+    park(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        const float *A = smem + (kt & 1) * (2 * 128 * LDT) + (wm + r) * LDT + g * 4;
+        const float *B = smem + (kt & 1) * (2 * 128 * LDT) + 128 * LDT + (wn + r) * LDT + g * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                av[i] = *reinterpret_cast<const f32x4 *>(A + i * 16 * LDT + h * 16);
+                bv[i] = *reinterpret_cast<const f32x4 *>(B + i * 16 * LDT + h * 16);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(av[i][e], bv[j][e], acc[i][j]);
+        }
+        if (more) park((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    const int m0 = mblk + wm, n0 = nblk + wn;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + j * 16 + r;
+        const float b = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m0 + i * 16 + g * 4 + e;
+                if (row < M) {
+                    float v = acc[i][j][e] + b;
+                    if (ACT == 1) v = elu1(v);
+                    y[out_index(row, col, N, ldy, frames_T, mt16, out_mode)] = v;
                 }
             }
     }
 }
 
 int launch_gemm_batched(const float *x, long long ldx, const float *w, long long ldw, const float *bias,
-                        int M, int N, int K, int act, float *y, long long ldy, hipStream_t s, long long frames_T) {
+                        int M, int N, int K, int act, float *y, long long ldy, hipStream_t s, int out_mode,
+                        long long frames_T, int mt16) {
     if (M <= 0) return BVC_OK;
     if (K % 16 || ldx % 4 || ldw % 4) {
         set_error("gemm_batched: K=%d ldx=%lld ldw=%lld must be multiples of 16/4/4", K, ldx, ldw);
         return BVC_EINVAL;
     }
+    if (out_mode != GO_NATURAL) {
+        const bool utt_rows = out_mode == GO_FRAME_MAJOR_ROWS || out_mode == GO_PACKED_FROM_UTT;
+        if (mt16 <= 0 || mt16 % 16 || N % 16 || (utt_rows && (frames_T <= 0 || M % frames_T || M / frames_T > mt16)) ||
+            (out_mode == GO_PACKED_FRAMES && M % mt16)) {
+            set_error("gemm_batched: inconsistent frame layout (M=%d T=%lld mt16=%d N=%d mode=%d)", M, frames_T, mt16, N, out_mode);
+            return BVC_EINVAL;
+        }
+    }
     dim3 grid((N + 127) / 128, (M + 127) / 128);
     ProbeScope probe(PK_BATCHED, s);
-    int mt16 = 0;
-    if (frames_T > 0) {
-        if (M % frames_T || N % 16) { set_error("gemm_batched: frame-packed output needs M %% T == 0, N %% 16 == 0"); return BVC_EINVAL; }
-        mt16 = (int)(((M / frames_T) + 15) / 16) * 16;
+    static const bool no_lds = getenv("BVC_NO_LDS_GEMM") != nullptr;      // A/B switch for the profiles
+    if (!no_lds && K % 32 == 0 && K >= 256 && N % 128 == 0) {
+        const size_t lds = (size_t)2 * 2 * 128 * 36 * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        if (act == 1)
+            hipLaunchKernelGGL(gemm_batched_lds_kernel<1>, grid, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode);
+        else
+            hipLaunchKernelGGL(gemm_batched_lds_kernel<0>, grid, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode);
+        BVC_HIP_TRY(hipGetLastError());
+        return BVC_OK;
     }
     if (act == 1)
-        hipLaunchKernelGGL(gemm_batched_kernel<1>, grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16);
+        hipLaunchKernelGGL(gemm_batched_kernel<1>, grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode);
     else
-        hipLaunchKernelGGL(gemm_batched_kernel<0>, grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16);
+        hipLaunchKernelGGL(gemm_batched_kernel<0>, grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }
