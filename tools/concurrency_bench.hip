@@ -13,7 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 constexpr int M = 64, N = 1024, K = 1024;
 
-template <int NW, int U, int MT>
+template <int NW, int U, int MT, int NT = 0>
 __global__ __launch_bounds__(NW * 64) void layer(const float *__restrict__ x, const float *__restrict__ w,
                                                  const float *__restrict__ bias, float *__restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][MT][256]
@@ -27,14 +27,18 @@ __global__ __launch_bounds__(NW * 64) void layer(const float *__restrict__ x, co
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nb = K / 16, lo = nb * wave / NW, hi = nb * (wave + 1) / NW;
-    for (int kb = lo; kb < hi; kb += U) {
+    for (int kb = lo; kb < ((NT & 4) ? lo : hi); kb += U) {      // NT & 4: no operand loads at all (fixed cost of a layer)
         f32x4 xv[U][MT], wv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            wv[u] = *reinterpret_cast<const f32x4 *>(w + (((size_t)ntile * nb + kb + u) * 64 + lane) * 4);
+            const f32x4 *wp_ = reinterpret_cast<const f32x4 *>(w + (((size_t)ntile * nb + kb + u) * 64 + lane) * 4);
+            wv[u] = (NT & 1) ? __builtin_nontemporal_load(wp_) : *wp_;
 #pragma unroll
             for (int j = 0; j < MT; ++j)
-                xv[u][j] = *reinterpret_cast<const f32x4 *>(x + (((size_t)(mg * MT + j) * nb + kb + u) * 64 + lane) * 4);
+            {
+                const f32x4 *xp_ = reinterpret_cast<const f32x4 *>(x + (((size_t)(mg * MT + j) * nb + kb + u) * 64 + lane) * 4);
+                xv[u][j] = (NT & 2) ? __builtin_nontemporal_load(xp_) : *xp_;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -65,14 +69,14 @@ __global__ __launch_bounds__(NW * 64) void layer(const float *__restrict__ x, co
 
 struct Chain { std::vector<float *> Wp; float *a, *b; hipStream_t s; hipGraph_t g; hipGraphExec_t ge; };
 
-template <int NW, int U, int MT>
+template <int NW, int U, int MT, int NT = 0>
 void run(const char *name, std::vector<Chain> &ch, float *bias, int C) {
     const int L = (int)ch[0].Wp.size(), REPLAY = 20;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(layer<NW, U, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, NW * MT * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(layer<NW, U, MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, NW * MT * 1024));
     for (int c = 0; c < C; ++c) {
         CK(hipStreamBeginCapture(ch[c].s, hipStreamCaptureModeThreadLocal));
         for (int l = 0; l < L; ++l)
-            hipLaunchKernelGGL((layer<NW, U, MT>), dim3(256 / MT), dim3(NW * 64), NW * MT * 1024, ch[c].s, (l & 1) ? ch[c].b : ch[c].a,
+            hipLaunchKernelGGL((layer<NW, U, MT, NT>), dim3(256 / MT), dim3(NW * 64), NW * MT * 1024, ch[c].s, (l & 1) ? ch[c].b : ch[c].a,
                                ch[c].Wp[l], bias, (l & 1) ? ch[c].a : ch[c].b);
         CK(hipStreamEndCapture(ch[c].s, &ch[c].g));
         CK(hipGraphInstantiate(&ch[c].ge, ch[c].g, nullptr, nullptr, 0));
@@ -107,12 +111,23 @@ int main() {
             CK(hipMalloc(&ch[c].Wp[l], hp.size() * 4));
             CK(hipMemcpy(ch[c].Wp[l], hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
         }
+        if (getenv("CB_SAMEW"))                 // every layer of every chain reads ONE 4 MB matrix: it stays in the L2s
+            for (int l = 0; l < L; ++l) ch[c].Wp[l] = ch[0].Wp[0];
         CK(hipMalloc(&ch[c].a, M * K * 4)); CK(hipMalloc(&ch[c].b, M * K * 4));
         CK(hipMemset(ch[c].a, 0, M * K * 4)); CK(hipMemset(ch[c].b, 0, M * K * 4));
         CK(hipStreamCreateWithFlags(&ch[c].s, hipStreamNonBlocking));
     }
     for (int C = 1; C <= CMAX; ++C) {
         run<8, 4, 1>("MT1 (256 WG x 8 waves)", ch, bias, C);
+        if (getenv("CB_VARIANTS")) {
+            run<8, 4, 1, 4>("MT1, no operand loads", ch, bias, C);
+            run<8, 4, 1, 1>("MT1, W loads nt", ch, bias, C);
+            run<8, 4, 1, 3>("MT1, W and X loads nt", ch, bias, C);
+            run<8, 8, 1>("MT1, 8 waves x U8", ch, bias, C);
+            run<16, 4, 1>("MT1, 16 waves x U4", ch, bias, C);
+            run<4, 8, 1>("MT1, 4 waves x U8", ch, bias, C);
+            continue;
+        }
         run<8, 4, 2>("MT2 (128 WG x 8 waves)", ch, bias, C);
         run<16, 4, 2>("MT2 (128 WG x 16 waves)", ch, bias, C);
         run<16, 4, 4>("MT4 (64 WG x 16 waves)", ch, bias, C);
