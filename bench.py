@@ -89,12 +89,13 @@ def pmc_traffic_bytes(kernel_prefix):
 
 
 def cpu_baseline(conf):
-    """Oracle (PyTorch-CPU port of the reference op sequence) on a bounded sample: 8 x 5 s."""
+    """Oracle (PyTorch-CPU port of the reference op sequence) on a bounded sample: 32 x 5 s, half the GPU
+    batch (about 10 s of CPU work on the box's 16 cores)."""
     from oracle import codec as ocodec
     threads = min(16, os.cpu_count() or 1)      # the 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(threads)
     oc = ocodec.OracleCodec(conf, synth.bvrnn_state_dict(conf, 1234), synth.generator_state_dict(conf, 1235))
-    b = 8
+    b = 32
     x = synth.synthetic_speech(b, int(FS * SECONDS), seed=0, kind="noise")
     oc.forward(x[:1, :FS], BITRATE)                                  # warm-up (thread pools, mkldnn)
     t0 = time.time()

@@ -366,6 +366,32 @@ def test_full_size_config_roundtrip_properties():
     assert float((w - ref_wav).pow(2).mean().sqrt()) < 1e-4
 
 
+def test_config3_per_gpu_shard_10s_three_bitrates():
+    """BASELINE configs[3]: the 64-utterance per-GPU shard of the 512 x 10 s job at 1500 / 3000 / 6000 bit/s, checked
+    through size-independent properties: bit-mask structure per bitrate (17 / 35 / 64 active bits), causality (the
+    first 5 s coded alone give the same codes for every frame that does not touch the right reflect padding), the
+    decoder's prefix property, and the bit-packed wire size."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    model = make_model(True, 1024)[0]
+    x = synth.synthetic_speech(64, 220500, seed=2, kind="noise").to(DEV)
+    half = 110250
+    for bitrate, nbits in ((1500, 17), (3000, 35), (6000, 64)):
+        codes = model.encode(x, bitrate)
+        assert codes.shape == (64, 861, 64)
+        assert (codes[:, :, nbits:] == 0.5).all() and (codes[:, :, :nbits] != 0.5).all()
+        assert model.active_bits(bitrate) == nbits
+        first = model.encode(x[:, :half], bitrate)                  # 430 frames; the last 2 see reflected samples
+        assert torch.equal(first[:, :428], codes[:, :428])
+        wav = model.decode(codes, 220500)
+        assert wav.shape == (64, 220500) and torch.isfinite(wav).all()
+        wav_half = model.decode(codes[:, :430].contiguous(), half)   # causal decoder: a prefix of the codes gives a prefix of the waveform
+        n = 256 * 430                                                 # samples past the last whole frame hold partial sums of later frames
+        assert (wav_half[:, :n] - wav[:, :n]).abs().max().item() <= 1e-6
+        packed = model.pack(codes, bitrate)
+        assert packed.shape == (64, 861, (nbits + 7) // 8) and torch.equal(model.unpack(packed, bitrate), codes)
+
+
 # ----------------------------------------------------------------------------------- BASELINE configs / edge cases
 def test_config0_single_10s_utterance_fixed_64bit():
     """BASELINE configs[0]: one 10 s utterance, config_64bit (bitrate ignored), against the oracle."""
