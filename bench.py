@@ -40,7 +40,7 @@ SECONDS = 5.0
 BITRATE = 3000
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix = vector peak
 PROBE_NAMES = {1: "gemm_skinny_kernel<1,1,8|16,4,1> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<3,2,16,2,1> (GRU cell)",
-               3: "amp_pair_kernel / conv_mfma_kernel (BigVGAN convs)", 4: "gemm_batched_kernel (phi_x / phi_z over all frames)",
+               3: "amp_pair_kernel / conv_mfma_kernel (BigVGAN convs)", 4: "gemm_batched_(lds_)kernel (phi_x / phi_z and the decoder's phi_z products over all frames)",
                5: "stft_logmel_kernel", 6: "conv_post_kernel"}
 
 
@@ -226,6 +226,12 @@ def main():
         _abi.check(lib.bvc_kprobe_enable(0))
         fam[1] = (fam[1][0] - 2.0 * B * T * (conf["z_dim"] * conf["h_dim"] + 2 * conf["h_dim"] ** 2), T * (13 + 7))
         fam[4] = (fam[4][0] + 2.0 * B * T * (conf["z_dim"] * conf["h_dim"] + 2 * conf["h_dim"] ** 2), 6)
+        if os.environ.get("BVC_NO_PRECOMP", "0") != "1" and os.environ.get("BVC_SIDE_BRANCH", "0") != "1":
+            # decode: the phi_z halves of dec.0 (H x H) and of the GRU input product (3H x H) are batched over all frames
+            hh = 2.0 * B * T * conf["h_dim"] ** 2
+            fam[1] = (fam[1][0] - hh, fam[1][1])
+            fam[2] = (fam[2][0] - 3 * hh, fam[2][1])
+            fam[4] = (fam[4][0] + 4 * hh, 8)
         for kind, mean, n in ((1, (e_lin * e_nl + d_lin * d_nl) / max(1, e_nl + d_nl), e_nl + d_nl),
                               (2, (e_gru * e_ng + d_gru * d_ng) / max(1, e_ng + d_ng), e_ng + d_ng)):
             fl, launches = fam[kind]

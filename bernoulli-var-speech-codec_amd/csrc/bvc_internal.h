@@ -36,7 +36,8 @@ struct ProbeScope {
 // kernel argument: caller tensors are reached through this descriptor and the frame index `t` is a
 // device-side counter advanced by step_advance_kernel at the end of every step.
 enum DescSlot { DS_PX = 0, DS_CODES = 1, DS_BITS = 2, DS_PROB = 3, DS_ALLH = 4, DS_MEL = 5, DS_PZ = 6, DS_NOISE = 7, DS_NSLOT = 8,
-                DS_PRIOR = DS_ALLH /* BVRNN.forward has no all_h output: the slot carries the prior probabilities */ };
+                DS_PRIOR = DS_ALLH /* BVRNN.forward has no all_h output: the slot carries the prior probabilities */,
+                DS_PARTD = DS_PX, DS_PARTG = DS_CODES /* decode has neither: pre-computed phi_z halves of dec.0 / of the GRU input */ };
 struct CallDesc {
     float *p[DS_NSLOT];              // base pointers of the (B, T, dim) tensors of this call (may be null)
     long long T;                     // frames per utterance
@@ -111,7 +112,8 @@ struct GemmParams {
     const float *bias0;        // group 0 bias [gates*N] (may be null)
     const float *bias1;        // group 1 bias (GRU only)
     DynPtr  y, y2, y3;         // outputs (y2/y3 optional); EPI_CODE with CS_SAMPLE: y2 = uniform noise INPUT
-    DynPtr  aux;               // CODE: bits per frame (one per row); GRU: previous h; ELU: optional addend
+    DynPtr  aux;               // CODE: bits per frame (one per row); GRU: previous h; LINEAR/ELU: optional addend (natural [M][N])
+                               // GRU: y3 (if valid) = pre-computed part of the input gates gi, natural [M][3*gate_rows]
     const float *part_i; const float *part_h; long long ldpart;   // GRU_PART: side-branch partial sums [M][3H]
     const float *mean; const float *stdv; // MEL epilogue
     const CallDesc *desc;      // null for stand-alone launches (all pointers static)

@@ -69,6 +69,7 @@ struct bvc_model {
     Linear prior[3];            // only used by bvc_bvrnn_forward; optional (has_prior)
     bool has_prior = false;
     const float *w_ih = nullptr, *w_hh = nullptr, *b_ih = nullptr, *b_hh = nullptr;     // w_*: fragment-packed
+    const float *w_ih_nat = nullptr;      // natural [3H][2H] copy: the phi_z half is applied to all frames at once in decode
     // vocoder
     ConvLayer conv_pre;
     std::vector<ConvLayer> ups;                       // n_up
@@ -84,6 +85,7 @@ struct bvc_model {
     bool side_branch = false;   // measured SLOWER on MI355X (cross-branch graph dependencies + no spare L2->CU bandwidth): opt-in
     bool use_graph = true;
     bool fused_amp = true;
+    bool precomp_pz = true;     // decode: the phi_z halves of dec.0 and of the GRU input product are batched over all frames
     int mtw = 1;                // 16-row tiles per workgroup in the recurrent kernels (BVC_MTW = 1 | 2 | 4)
 
     ~bvc_model() {
@@ -288,6 +290,7 @@ int build_bvrnn(bvc_model *m, const TensorMap &tm) {
     }
     if (!(t = find(tm, "rnn.weight_ih_l0", (int64_t)3 * H * 2 * H))) return BVC_EMISSING;
     if ((rc = upload(m, pack_linear(t->h_data, 3 * H, 2 * H), &m->w_ih))) return rc;
+    if ((rc = upload_raw(m, t->h_data, t->numel, &m->w_ih_nat))) return rc;
     if (!(t = find(tm, "rnn.weight_hh_l0", (int64_t)3 * H * H))) return BVC_EMISSING;
     if ((rc = upload(m, pack_linear(t->h_data, 3 * H, H), &m->w_hh))) return rc;
     if (!(t = find(tm, "rnn.bias_ih_l0", 3 * H))) return BVC_EMISSING;
@@ -390,6 +393,7 @@ struct Workspace {
     float *part_i, *part_h, *part_d;   // side-branch partial sums: W_ih[:,H:] phi_z + b_ih, W_hh h + b_hh, dec.0[:,H:] h
     CallDesc *desc;             // per-call dynamic state read by the captured step kernels
     float *mel, *bits;          // facade-level buffers
+    float *part_dec0, *part_gru; // decode: dec.0[:, :H] phi_z + b (B,T,H) and W_ih[:, H:] phi_z + b_ih (B,T,3H), all frames
     // vocoder
     float *y0, *X, *P, *Q, *U, *XS;
     size_t total;
@@ -427,6 +431,8 @@ void carve(const bvc_model *m, int B, int64_t T, char *base, Workspace *w) {
     w->pxC = take(mt16 * (size_t)T * H);
     w->mel = take(BT * c.num_mels);
     w->bits = take(BT);
+    w->part_dec0 = take(BT * H);
+    w->part_gru = take(BT * 3 * H);
     size_t maxel = 0;
     for (int i = 0; i < c.n_up; ++i) {
         const size_t e = (size_t)stage_len(m, T, i) * m->stage_ch[i];
@@ -566,6 +572,13 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
         p.aux = dp_static(w.part_d, H);
         WAIT(BR_MAIN, EV_DEC0H);
         K(BR_MAIN, p, EPI_ELU);
+    } else if (kind == STEP_DECODE && m->precomp_pz) {
+        // dec.0([phi_z, h]) = (dec.0[:, :H] phi_z + b) [all frames, batched] + dec.0[:, H:] h
+        GemmParams p = lin_params(m->dec[0], h_cur, B, S(d1, H));
+        p.seg[0] = mkseg(h_cur, m->dec[0].wp + (size_t)(H / 16) * 256, 2 * H / 16, H, 0);
+        p.bias0 = nullptr;
+        p.aux = dp_frame(DS_PARTD, H);
+        K(BR_MAIN, p, EPI_ELU);
     } else {
         K(BR_MAIN, lin2_params(m->dec[0], pz_final, H, h_cur, H, B, S(d1, H)), EPI_ELU);
     }
@@ -593,6 +606,13 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
             p.part_i = w.part_i; p.part_h = w.part_h; p.ldpart = 3LL * H;
             WAIT(BR_MAIN, EV_GATES);
             K(BR_MAIN, p, EPI_GRU_PART);
+        } else if (kind == STEP_DECODE && m->precomp_pz) {
+            p.nseg = 2;                                                               // W_ih[:, H:] phi_z + b_ih comes in through y3
+            p.seg[0] = mkseg(S(g3, H), m->w_ih, 2 * H / 16, H, 0);
+            p.seg[1] = mkseg(h_cur, m->w_hh, H / 16, H, 1);
+            p.bias0 = nullptr; p.bias1 = m->b_hh;
+            p.y3 = dp_frame(DS_PARTG, 3 * H);
+            K(BR_MAIN, p, EPI_GRU);
         } else {
             p.nseg = 3;
             p.seg[0] = mkseg(S(g3, H), m->w_ih, 2 * H / 16, H, 0);                    // cat([phi_x_gen, phi_z]) bvrnn.py:206
@@ -793,11 +813,24 @@ int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     const int H = m->cfg.h_dim, Z = m->cfg.z_dim;
     int rc;
     // phi_z depends on the codes only: all frames at once, outside the recurrence (bvrnn.py:223)
-    if ((rc = batched_mlp3(m, w, m->phi_z, d_codes, Z, B, T, s))) return rc;
-    if ((rc = init_state(w, d_h0, B, H, s))) return rc;
     CallDesc d;
     memset(&d, 0, sizeof(d));
-    d.p[DS_PZ] = w.pxA; d.p[DS_MEL] = d_mel;
+    if (m->precomp_pz) {
+        // ... and so do the phi_z halves of dec.0 (bvrnn.py:224) and of the GRU's input product (bvrnn.py:227): two more
+        // batched GEMMs (89 TFLOP/s) take 4 of the 15.4 layer-equivalents per frame out of the recurrence (29 TFLOP/s)
+        const int BT = (int)((long long)B * T);
+        if ((rc = launch_gemm_batched(d_codes, Z, m->phi_z[0].w, Z, m->phi_z[0].b, BT, H, Z, 1, w.pxC, H, s))) return rc;
+        if ((rc = launch_gemm_batched(w.pxC, H, m->phi_z[1].w, H, m->phi_z[1].b, BT, H, H, 1, w.pxB, H, s))) return rc;
+        if ((rc = launch_gemm_batched(w.pxB, H, m->phi_z[2].w, H, m->phi_z[2].b, BT, H, H, 1, w.pxC, H, s))) return rc;
+        if ((rc = launch_gemm_batched(w.pxC, H, m->dec[0].w, 2 * H, m->dec[0].b, BT, H, H, 0, w.part_dec0, H, s))) return rc;
+        if ((rc = launch_gemm_batched(w.pxC, H, m->w_ih_nat + H, 2 * H, m->b_ih, BT, 3 * H, H, 0, w.part_gru, 3 * H, s))) return rc;
+        d.p[DS_PARTD] = w.part_dec0; d.p[DS_PARTG] = w.part_gru;
+    } else {
+        if ((rc = batched_mlp3(m, w, m->phi_z, d_codes, Z, B, T, s))) return rc;
+        d.p[DS_PZ] = w.pxA;
+    }
+    if ((rc = init_state(w, d_h0, B, H, s))) return rc;
+    d.p[DS_MEL] = d_mel;
     d.T = T;
     if ((rc = begin_call(m, w, d, count_kernels(build_step(m, w, B, STEP_DECODE)), s))) return rc;
     if ((rc = run_recurrence(m, w, ws_base, B, T, STEP_DECODE, s))) return rc;
@@ -1117,6 +1150,8 @@ int bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t n
         if (mw && (mw[0] == '2' || mw[0] == '4')) m->mtw = mw[0] - '0';
         const char *ua = getenv("BVC_UNFUSED_AMP");
         m->fused_amp = !(ua && ua[0] == '1');
+        const char *np = getenv("BVC_NO_PRECOMP");
+        m->precomp_pz = !(np && np[0] == '1') && !m->side_branch;
     }
     if ((rc = build_frontend(m.get(), tm))) return rc;
     if ((rc = build_bvrnn(m.get(), tm))) return rc;

@@ -247,7 +247,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
         const Resolved y = resolve(p.y, dsc, mt16, p.tstep);
         if (epi == EPI_LINEAR || epi == EPI_ELU) {
             float o = v[0];
-            if (p.aux.base) o += p.aux.base[(long long)m * p.aux.ld + n];     // pre-computed half of a split dot product
+            if (p.aux.base || (p.aux.meta & 15)) {                            // pre-computed half of a split dot product
+                const Resolved ad = resolve(p.aux, dsc, mt16, p.tstep);
+                o += ad.p[(long long)m * ad.ld + n];
+            }
             if (epi == EPI_ELU) o = elu1(o);
             store_out(y, m, n, o);
         } else if (epi == EPI_SIGMOID) {
@@ -298,8 +301,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
           }
         } else if (epi == EPI_GRU) {
           if constexpr (NG == 3 && NGRP == 2) {
-            const float gi_r = v[0], gi_z = v[1], gi_n = v[2];
+            float gi_r = v[0], gi_z = v[1], gi_n = v[2];
             const float gh_r = v[3], gh_z = v[4], gh_n = v[5];
+            if (p.y3.meta & 15) {                                            // W_ih[:, H:] phi_z + b_ih, batched over all frames
+                const Resolved pg = resolve(p.y3, dsc, mt16, p.tstep);
+                const float *q = pg.p + (long long)m * pg.ld + n;
+                gi_r += q[0]; gi_z += q[p.gate_rows]; gi_n += q[2 * p.gate_rows];
+            }
             const float rg = sigmoid1(gh_r + gi_r);
             const float zg = sigmoid1(gh_z + gi_z);
             const float ng = tanhf(gi_n + rg * gh_n);

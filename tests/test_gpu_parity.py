@@ -481,3 +481,9 @@ def test_execution_variants_agree(env):
     mel_a, _ = base.bvrnn.decode(codes, torch.zeros(1, 5, 1024, device=DEV))
     mel_b, _ = side.bvrnn.decode(codes, torch.zeros(1, 5, 1024, device=DEV))
     assert (mel_a - mel_b).abs().max().item() < 1e-5
+    # default decode batches the phi_z halves of dec.0 / the GRU input product over all frames; BVC_NO_PRECOMP=1 keeps
+    # them inside the recurrence: one more rounding per split dot product
+    inrec = make_model(True, 1024, env={"BVC_NO_PRECOMP": "1"})[0]
+    mel_c, h_c = inrec.bvrnn.decode(codes, torch.zeros(1, 5, 1024, device=DEV))
+    assert (mel_a - mel_c).abs().max().item() < 1e-5
+    assert torch.equal(inrec.encode(x, 3000), codes)
