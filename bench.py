@@ -109,7 +109,7 @@ def cpu_baseline(conf):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=SECONDS)
