@@ -261,7 +261,10 @@ def main():
                            "timer": r["timer"],
                            "rocprof_avg_us": "5.0 (rocprofv3 --kernel-trace, dispatch-inclusive, --streams 1: profiles/r01_l_kernel_stats_final_1stream.csv)",
                            "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32); algorithmic FLOPs per launch / "
-                                   "launch duration measured in situ inside the real schedule"}
+                                   "launch duration measured in situ inside the real schedule.  The layer is not MFMA-limited: "
+                                   "each 16x16 output tile pulls 128 KB of operands through its CU's L1, and chains of this "
+                                   "layer shape saturate the chip at 0.37 layers/us = 50 TFLOP/s whatever the tiling "
+                                   "(profiles/r01_concurrency_microbench.txt)"}
         out["kernel_families"] = rows
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(conf)
