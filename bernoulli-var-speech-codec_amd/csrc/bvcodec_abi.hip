@@ -490,7 +490,8 @@ GemmParams lin2_params(const Linear &l, DynPtr x1, int K1, DynPtr x2, int K2, in
 enum { OP_KERNEL = 0, OP_RECORD = 1, OP_WAIT = 2 };
 enum { BR_MAIN = 0, BR_SIDE = 1 };
 struct StepNode { int op; int branch; int event; GemmParams p; int epi; };
-enum { STEP_ENCODE = 0, STEP_DECODE = 1 };
+enum { STEP_ENCODE = 0, STEP_DECODE = 1, STEP_DECODE_PRE = 2 };   // _PRE: phi_z halves of dec.0 / GRU arrive pre-computed
+constexpr int64_t PRECOMP_MIN_FRAMES = 16;     // below this (streaming hops) the two extra batched GEMMs cost more than they save
 enum { EV_START = 0, EV_DEC0H = 1, EV_PZ = 2, EV_GATES = 3, EV_COUNT = 4 };
 
 // The operation sequence of ONE frame.  Every pointer is either workspace-static, frame-indexed through
@@ -572,7 +573,7 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
         p.aux = dp_static(w.part_d, H);
         WAIT(BR_MAIN, EV_DEC0H);
         K(BR_MAIN, p, EPI_ELU);
-    } else if (kind == STEP_DECODE && m->precomp_pz) {
+    } else if (kind == STEP_DECODE_PRE) {
         // dec.0([phi_z, h]) = (dec.0[:, :H] phi_z + b) [all frames, batched] + dec.0[:, H:] h
         GemmParams p = lin_params(m->dec[0], h_cur, B, S(d1, H));
         p.seg[0] = mkseg(h_cur, m->dec[0].wp + (size_t)(H / 16) * 256, 2 * H / 16, H, 0);
@@ -586,7 +587,7 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
     K(BR_MAIN, lin_params(m->dec[1], S(d1, H), B, S(d2, H)), EPI_ELU);
     K(BR_MAIN, lin_params(m->dec[2], S(d2, H), B, S(d3, H)), EPI_ELU);
     {
-        GemmParams p = lin_params(m->dec[3], S(d3, H), B, kind == STEP_DECODE ? dp_frame(DS_MEL, X) : dp_null());
+        GemmParams p = lin_params(m->dec[3], S(d3, H), B, kind != STEP_ENCODE ? dp_frame(DS_MEL, X) : dp_null());
         p.y2 = S(dn, X); p.mean = m->mean_mel; p.stdv = m->std_mel;
         K(BR_MAIN, p, EPI_MEL);
     }
@@ -606,7 +607,7 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
             p.part_i = w.part_i; p.part_h = w.part_h; p.ldpart = 3LL * H;
             WAIT(BR_MAIN, EV_GATES);
             K(BR_MAIN, p, EPI_GRU_PART);
-        } else if (kind == STEP_DECODE && m->precomp_pz) {
+        } else if (kind == STEP_DECODE_PRE) {
             p.nseg = 2;                                                               // W_ih[:, H:] phi_z + b_ih comes in through y3
             p.seg[0] = mkseg(S(g3, H), m->w_ih, 2 * H / 16, H, 0);
             p.seg[1] = mkseg(h_cur, m->w_hh, H / 16, H, 1);
@@ -815,7 +816,9 @@ int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     // phi_z depends on the codes only: all frames at once, outside the recurrence (bvrnn.py:223)
     CallDesc d;
     memset(&d, 0, sizeof(d));
-    if (m->precomp_pz) {
+    const bool pre = m->precomp_pz && T >= PRECOMP_MIN_FRAMES;
+    const int kind = pre ? STEP_DECODE_PRE : STEP_DECODE;
+    if (pre) {
         // ... and so do the phi_z halves of dec.0 (bvrnn.py:224) and of the GRU's input product (bvrnn.py:227): two more
         // batched GEMMs (89 TFLOP/s) take 4 of the 15.4 layer-equivalents per frame out of the recurrence (29 TFLOP/s)
         const int BT = (int)((long long)B * T);
@@ -832,8 +835,8 @@ int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     if ((rc = init_state(w, d_h0, B, H, s))) return rc;
     d.p[DS_MEL] = d_mel;
     d.T = T;
-    if ((rc = begin_call(m, w, d, count_kernels(build_step(m, w, B, STEP_DECODE)), s))) return rc;
-    if ((rc = run_recurrence(m, w, ws_base, B, T, STEP_DECODE, s))) return rc;
+    if ((rc = begin_call(m, w, d, count_kernels(build_step(m, w, B, kind)), s))) return rc;
+    if ((rc = run_recurrence(m, w, ws_base, B, T, kind, s))) return rc;
     if (d_hT && (rc = read_state(w, B, H, T, d_hT, s))) return rc;
     return BVC_OK;
 }

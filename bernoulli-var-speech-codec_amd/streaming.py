@@ -3,7 +3,8 @@ BASELINE.json configs[4]).
 
 The reference facade has no streaming mode: it zero-initialises the GRU state on every call
 (bvrnn_codec_model.py:60,69) and never returns the state after the last frame (bvrnn.py:205).  The
-primitives are causal, though, so chunked processing is exact:
+primitives are causal, though, so chunked processing reproduces the offline result (code bits identical; waveform
+to rounding, <= 1e-6 - long offline decodes batch two dot-product halves over all frames, short hops do not):
 
 * front-end: frame t reads samples [256t-256, 256t+768) -> it is emitted as soon as those samples
   have arrived (algorithmic look-ahead 768 samples = 34.8 ms, README.md:19); the last frames of an
