@@ -64,6 +64,34 @@ __device__ __forceinline__ float snakebeta(float x, float a, float ib) {
     return __fadd_rn(x, __fmul_rn(ib, sin_squared(__fmul_rn(x, a))));
 }
 
+// Two elements per lane: the same operations as sin_squared / snakebeta on both halves (bit-identical results),
+// written on 2-vectors so that the multiplies and fused multiply-adds become packed-fp32 instructions
+// (v_pk_mul_f32 / v_pk_fma_f32: two fp32 lanes per instruction at full rate) - SnakeBeta is ~40 % of the
+// generator's vector instructions and shares the SIMD's issue slots with the MFMAs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
+__device__ __forceinline__ f32x2 sin_squared2(f32x2 x) {
+    f32x2 k = x * splat2(0.636619772367581343f);
+    k = (f32x2){rintf(k[0]), rintf(k[1])};
+    const f32x2 nk = -k;
+    f32x2 r = __builtin_elementwise_fma(nk, splat2(1.57079625129699707031e+00f), x);
+    r = __builtin_elementwise_fma(nk, splat2(7.54978941586159635335e-08f), r);
+    r = __builtin_elementwise_fma(nk, splat2(5.39030252995776476554e-15f), r);
+    const f32x2 u = r * r;
+    f32x2 p = __builtin_elementwise_fma(splat2(1.345194032182917e-4f), u, splat2(-3.1710113398730755e-3f));
+    p = __builtin_elementwise_fma(p, u, splat2(4.444364085793495e-2f));
+    p = __builtin_elementwise_fma(p, u, splat2(-3.33333283662796e-1f));
+    p = __builtin_elementwise_fma(p, u, splat2(1.0f));
+    const f32x2 s2 = p * u;
+    const f32x2 c2 = splat2(1.0f) - s2;
+    return (f32x2){(((int)k[0]) & 1) ? c2[0] : s2[0], (((int)k[1]) & 1) ? c2[1] : s2[1]};
+}
+__device__ __forceinline__ f32x2 snakebeta2(f32x2 x, f32x2 a, f32x2 ib) {
+#pragma clang fp contract(off)
+    const f32x2 q = ib * sin_squared2(x * a);
+    return x + q;
+}
+
 // CIN: input channels; NTW: 16-column tiles per workgroup; MT: 16-row tiles per wave.
 template <int CIN, int NTW, int MT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
@@ -92,7 +120,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 const f32x4 aa = *reinterpret_cast<const f32x4 *>(a.act_a + c4 * 4);
                 const f32x4 bb = *reinterpret_cast<const f32x4 *>(a.act_ib + c4 * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = snakebeta(v[e], aa[e], bb[e]);
+                for (int e = 0; e < 4; e += 2) {
+                    const f32x2 o2 = snakebeta2((f32x2){v[e], v[e + 1]}, (f32x2){aa[e], aa[e + 1]}, (f32x2){bb[e], bb[e + 1]});
+                    v[e] = o2[0]; v[e + 1] = o2[1];
+                }
             }
         }
         float2 *dst = reinterpret_cast<float2 *>(tile + row * S + c4 * 4);
@@ -244,7 +275,10 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
                 const f32x4 bb = *reinterpret_cast<const f32x4 *>(a.ib1 + c4 * 4);
                 f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = snakebeta(v[i][e], aa[e], bb[e]);   // S(0) = 0 keeps the zero padding
+                for (int e = 0; e < 4; e += 2) {                                        // S(0) = 0 keeps the zero padding
+                    const f32x2 o2 = snakebeta2((f32x2){v[i][e], v[i][e + 1]}, (f32x2){aa[e], aa[e + 1]}, (f32x2){bb[e], bb[e + 1]});
+                    o[e] = o2[0]; o[e + 1] = o2[1];
+                }
                 float2 *dst = reinterpret_cast<float2 *>(t1 + row * S + c4 * 4);
                 dst[0] = make_float2(o[0], o[1]);
                 dst[1] = make_float2(o[2], o[3]);
@@ -356,10 +390,12 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; e += 2) {
                     const int row = mbase + i * 16 + g * 4 + e;
-                    const float u = acc[i][n][e] + bias;
-                    t2[row * S + col] = (tbase + row + a.t_origin >= 0) ? snakebeta(u, aa, bb) : 0.0f;
+                    const f32x2 u2 = (f32x2){acc[i][n][e] + bias, acc[i][n][e + 1] + bias};
+                    const f32x2 s2 = snakebeta2(u2, splat2(aa), splat2(bb));
+                    t2[row * S + col] = (tbase + row + a.t_origin >= 0) ? s2[0] : 0.0f;
+                    t2[(row + 1) * S + col] = (tbase + row + 1 + a.t_origin >= 0) ? s2[1] : 0.0f;
                 }
         }
     }
