@@ -382,21 +382,40 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     PHASE(1);
     if (ALIAS) __syncthreads();                            // every wave is done with S1(x): its LDS becomes t2
     for (int idx = tid; idx < (ks - 1) * S; idx += 256) t2[TR * S + idx] = 0.0f;    // spare rows read by discarded outputs
+    if constexpr (C == 8) {
+        // Only 8 of the tile's 16 columns exist: lanes r >= 8 hold padding.  They take over rows g*4+2, g*4+3 of
+        // column r-8 from their neighbour 8 lanes down (DPP row_shr:8), so that every lane evaluates ONE SnakeBeta
+        // pair per row tile instead of half the lanes evaluating two.
+        const int col = r & 7, e0 = (r >> 3) * 2;
+        const float bias = a.b1[col], aa = a.a2[col], bb = a.ib2[col];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int col = n * 16 + r;
-        if (col < C) {
-            const float bias = a.b1[col], aa = a.a2[col], bb = a.ib2[col];
+        for (int i = 0; i < MT; ++i) {
+            const float a0 = acc[i][0][0], a1 = acc[i][0][1], a2 = acc[i][0][2], a3 = acc[i][0][3];
+            const float hi0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a2), 0x118, 0xf, 0xf, false));   // row_shr:8
+            const float hi1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a3), 0x118, 0xf, 0xf, false));
+            const float v0 = r < 8 ? a0 : hi0, v1 = r < 8 ? a1 : hi1;
+            const int row = mbase + i * 16 + g * 4 + e0;
+            const f32x2 s2 = snakebeta2((f32x2){v0 + bias, v1 + bias}, splat2(aa), splat2(bb));
+            t2[row * S + col] = (tbase + row + a.t_origin >= 0) ? s2[0] : 0.0f;
+            t2[(row + 1) * S + col] = (tbase + row + 1 + a.t_origin >= 0) ? s2[1] : 0.0f;
+        }
+    } else {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+        for (int n = 0; n < NT; ++n) {
+            const int col = n * 16 + r;
+            if (col < C) {
+                const float bias = a.b1[col], aa = a.a2[col], bb = a.ib2[col];
 #pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const int row = mbase + i * 16 + g * 4 + e;
-                    const f32x2 u2 = (f32x2){acc[i][n][e] + bias, acc[i][n][e + 1] + bias};
-                    const f32x2 s2 = snakebeta2(u2, splat2(aa), splat2(bb));
-                    t2[row * S + col] = (tbase + row + a.t_origin >= 0) ? s2[0] : 0.0f;
-                    t2[(row + 1) * S + col] = (tbase + row + 1 + a.t_origin >= 0) ? s2[1] : 0.0f;
-                }
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const int row = mbase + i * 16 + g * 4 + e;
+                        const f32x2 u2 = (f32x2){acc[i][n][e] + bias, acc[i][n][e + 1] + bias};
+                        const f32x2 s2 = snakebeta2(u2, splat2(aa), splat2(bb));
+                        t2[row * S + col] = (tbase + row + a.t_origin >= 0) ? s2[0] : 0.0f;
+                        t2[(row + 1) * S + col] = (tbase + row + 1 + a.t_origin >= 0) ? s2[1] : 0.0f;
+                    }
+            }
         }
     }
     __syncthreads();
