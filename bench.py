@@ -39,7 +39,7 @@ BATCH = 64
 SECONDS = 5.0
 BITRATE = 3000
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix = vector peak
-PROBE_NAMES = {1: "gemm_skinny_kernel<1,1,8|16,4,1> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<3,2,16,2,1> (GRU cell)",
+PROBE_NAMES = {1: "gemm_skinny_kernel<1,1,8|12,1,1> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<3,2,12,1,1,gate-interleaved> (GRU cell)",
                3: "amp_pair_kernel / conv_mfma_kernel (BigVGAN convs)", 4: "gemm_batched_(lds_)kernel (phi_x / phi_z and the decoder's phi_z products over all frames)",
                5: "stft_logmel_kernel", 6: "conv_post_kernel"}
 
@@ -265,6 +265,14 @@ def main():
                                    "each 16x16 output tile pulls 128 KB of operands through its CU's L1, and chains of this "
                                    "layer shape saturate the chip at 0.37 layers/us = 50 TFLOP/s whatever the tiling "
                                    "(profiles/r01_concurrency_microbench.txt)"}
+        # SURVEY.md 8(d) also asks for the whole path against the fp32 peak: algorithmic FLOPs of a step (all families)
+        # over the measured step time of the timed region (the kernels of the three streams overlap, so this is not the
+        # sum of the per-launch figures above)
+        step_flops = sum(f for f, _ in flops_per_step(conf, B, T).values())
+        whole = step_flops / (elapsed / a.steps) / 1e12
+        out["roofline"]["whole_path"] = {"achieved": round(whole, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": round(whole / PEAK_FP32_MFMA_TFLOPS, 4),
+                                         "gflop_per_audio_second": round(step_flops / (B * a.seconds) / 1e9, 3)}
         out["kernel_families"] = rows
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(conf)

@@ -108,7 +108,7 @@ struct GemmParams {
     int     nseg;
     int     var_bit;
     int     sample;            // EPI_CODE: CodeSample
-    int     pad_;
+    int     gate_il;           // weights are gate-interleaved [n/16][k/16][gate][lane][4] (GRU launches)
     const float *bias0;        // group 0 bias [gates*N] (may be null)
     const float *bias1;        // group 1 bias (GRU only)
     DynPtr  y, y2, y3;         // outputs (y2/y3 optional); EPI_CODE with CS_SAMPLE: y2 = uniform noise INPUT

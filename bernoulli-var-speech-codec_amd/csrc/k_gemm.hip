@@ -83,7 +83,7 @@ __device__ __forceinline__ void store_out(const Resolved &y, int m, int n, float
 // load of a line another kernel has just written), whose latency is thus hidden behind the weights.
 // MTW row tiles share every weight fragment in registers (weights cross the L2->CU path once per MTW*16 rows).
 template <int NG, int U, int MTW>
-__device__ __forceinline__ void run_segment(const float *wl, long long gate_stride, const DynPtr &xd,
+__device__ __forceinline__ void run_segment(const float *wl, long long gate_stride, long long kbs, const DynPtr &xd,
                                             const CallDesc *dsc, int mt16, int tstep, const int (&mtile)[MTW],
                                             const int (&xrow)[MTW], int lane, int g, int lo, int hi,
                                             f32x4 (&acc)[MTW][NG]) {
@@ -107,7 +107,7 @@ __device__ __forceinline__ void run_segment(const float *wl, long long gate_stri
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int q = 0; q < NG; ++q)
-                wv[u][q] = *reinterpret_cast<const f32x4 *>(wl + (long long)q * gate_stride + (long long)(kb + u) * 256);
+                wv[u][q] = *reinterpret_cast<const f32x4 *>(wl + (long long)q * gate_stride + (long long)(kb + u) * kbs);
         if (!have_x) resolve_x();
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -128,7 +128,7 @@ __device__ __forceinline__ void run_segment(const float *wl, long long gate_stri
         f32x4 wv[NG];
 #pragma unroll
         for (int q = 0; q < NG; ++q)
-            wv[q] = *reinterpret_cast<const f32x4 *>(wl + (long long)q * gate_stride + (long long)kb * 256);
+            wv[q] = *reinterpret_cast<const f32x4 *>(wl + (long long)q * gate_stride + (long long)kb * kbs);
         if (!have_x) resolve_x();
 #pragma unroll
         for (int j = 0; j < MTW; ++j) {
@@ -141,7 +141,7 @@ __device__ __forceinline__ void run_segment(const float *wl, long long gate_stri
     }
 }
 
-template <int NG, int NGRP, int NW, int U, int MTW>
+template <int NG, int NGRP, int NW, int U, int MTW, bool GIL = false>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int epi) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][NGRP*NG][MTW][256]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -202,15 +202,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
         lo = lo < 0 ? 0 : lo;
         hi = hi > sb ? sb : hi;
         if (lo < hi) {
-            const long long gate_stride = (long long)(p.gate_rows >> 4) * p.seg[s].wnb * 256;      // floats between gates
-            const float *wl = p.seg[s].w + (long long)ntile * p.seg[s].wnb * 256 + lane * 4;
+            // floats between k-blocks / between gates: [n/16][k/16][lane][4] per gate, or gate-interleaved [n/16][k/16][gate][lane][4]
+            constexpr long long kbs = GIL ? NG * 256 : 256;
+            const long long gate_stride = GIL ? 256 : (long long)(p.gate_rows >> 4) * p.seg[s].wnb * 256;
+            const float *wl = p.seg[s].w + (long long)ntile * p.seg[s].wnb * kbs + lane * 4;
             if constexpr (NGRP == 1) {
-                run_segment<NG, U, MTW>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
+                run_segment<NG, U, MTW>(wl, gate_stride, kbs, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
             } else {
                 if (p.seg[s].grp == 0)
-                    run_segment<NG, U, MTW>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
+                    run_segment<NG, U, MTW>(wl, gate_stride, kbs, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
                 else
-                    run_segment<NG, U, MTW>(wl, gate_stride, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc1);
+                    run_segment<NG, U, MTW>(wl, gate_stride, kbs, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc1);
             }
         }
         base += sb;
@@ -328,12 +330,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
     }
 }
 
-template <int NG, int NGRP, int NW, int U, int MTW>
+template <int NG, int NGRP, int NW, int U, int MTW, bool GIL = false>
 static void launch_skinny_t(const GemmParams &p, int epi, hipStream_t s) {
     const int n_tiles = p.N / 16, m_tiles = (p.M + 15) / 16, m_groups = (m_tiles + MTW - 1) / MTW;
     const int grid = 8 * ((n_tiles + 7) / 8) * m_groups;
     const size_t lds = (size_t)NW * NG * NGRP * MTW * 256 * sizeof(float);
-    hipLaunchKernelGGL((gemm_skinny_kernel<NG, NGRP, NW, U, MTW>), dim3(grid), dim3(NW * 64), lds, s, p, epi);
+    hipLaunchKernelGGL((gemm_skinny_kernel<NG, NGRP, NW, U, MTW, GIL>), dim3(grid), dim3(NW * 64), lds, s, p, epi);
 }
 
 template <typename K>
@@ -344,9 +346,11 @@ static int allow_lds(K kern, int bytes) {
 
 int skinny_kernels_init() {
     int rc;
-    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 16, 2, 1>, 16 * 6 * 1024))) return rc;
-    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 8, 3, 2>, 8 * 6 * 2 * 1024))) return rc;
-    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 4, 2, 4>, 4 * 6 * 4 * 1024))) return rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 16, 1, 1, true>, 16 * 6 * 1024))) return rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 16, 1, 1, false>, 16 * 6 * 1024))) return rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 12, 1, 1, true>, 12 * 6 * 1024))) return rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 8, 3, 2, true>, 8 * 6 * 2 * 1024))) return rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 4, 2, 4, true>, 4 * 6 * 4 * 1024))) return rc;
     if ((rc = allow_lds(gemm_skinny_kernel<1, 1, 16, 4, 4>, 16 * 4 * 1024))) return rc;
     return BVC_OK;
 }
@@ -372,23 +376,35 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s, int mtw) {
     const int m_tiles = (p.M + 15) / 16;
     if (mtw > m_tiles) mtw = m_tiles >= 4 ? 4 : (m_tiles >= 2 ? 2 : 1);
     if (mtw != 2 && mtw != 4) mtw = 1;
+    // How many k-blocks a wave keeps in flight is a trade between one chain and several: chunks of 4 give the shortest
+    // single launch (4.0 us, 4,180 audio-s/s on one stream) but their load bursts crowd out the other streams' kernels;
+    // chunks of 1 (8 waves; 12 waves at K = 2048) take 4.7 us alone (3,860) and give 6,450 instead of 6,100 audio-s/s
+    // with three chains in flight.  Default: throughput; BVC_LATENCY=1 selects the single-chain optimum.
+    static const bool latency_mode = getenv("BVC_LATENCY") != nullptr && getenv("BVC_LATENCY")[0] == '1';
     ProbeScope probe((epi == EPI_GRU || epi == EPI_GRU_PART) ? PK_GRU : PK_LINEAR, s);
+    if (p.gate_il && epi != EPI_GRU) { set_error("gemm_skinny: gate-interleaved weights are for the GRU launch only"); return BVC_EINVAL; }
     if (epi == EPI_GRU) {
-        if (mtw == 4)      launch_skinny_t<3, 2, 4, 2, 4>(p, epi, s);
-        else if (mtw == 2) launch_skinny_t<3, 2, 8, 3, 2>(p, epi, s);
-        else               launch_skinny_t<3, 2, 16, 2, 1>(p, epi, s);
+        // chunks of ONE k-block: 15.3 us against 17.0 us with chunks of two (and 0.082 against 0.061 launches/us with three
+        // chains in tools/gru_splitk_bench.hip): a 16-wave workgroup that bursts 8 KiB of loads per wave only queues them
+        if (!p.gate_il)    launch_skinny_t<3, 2, 16, 1, 1, false>(p, epi, s);
+        else if (mtw == 4) launch_skinny_t<3, 2, 4, 2, 4, true>(p, epi, s);
+        else if (mtw == 2) launch_skinny_t<3, 2, 8, 3, 2, true>(p, epi, s);
+        else if (latency_mode) launch_skinny_t<3, 2, 16, 1, 1, true>(p, epi, s);
+        else                   launch_skinny_t<3, 2, 12, 1, 1, true>(p, epi, s);     // 12 waves: +2 % over 16 with three chains in flight
     } else if (epi == EPI_GRU_PART) {
         launch_skinny_t<3, 1, 8, 4, 1>(p, epi, s);
     } else if (nb >= 128) {          // K >= 2048: 16 waves
         if (mtw == 4)      launch_skinny_t<1, 1, 16, 4, 4>(p, epi, s);
         else if (mtw == 2) launch_skinny_t<1, 1, 16, 8, 2>(p, epi, s);
-        else               launch_skinny_t<1, 1, 16, 4, 1>(p, epi, s);
+        else if (latency_mode) launch_skinny_t<1, 1, 16, 4, 1>(p, epi, s);
+        else                   launch_skinny_t<1, 1, 12, 1, 1>(p, epi, s);
     } else {
         // mtw 1: chunks of 4 k-blocks (52 VGPRs) measured 2 % faster than chunks of 8 (88 VGPRs), alone and
         // with three chains in flight
         if (mtw == 4)      launch_skinny_t<1, 1, 8, 4, 4>(p, epi, s);
         else if (mtw == 2) launch_skinny_t<1, 1, 8, 8, 2>(p, epi, s);
-        else               launch_skinny_t<1, 1, 8, 4, 1>(p, epi, s);
+        else if (latency_mode) launch_skinny_t<1, 1, 8, 4, 1>(p, epi, s);
+        else                   launch_skinny_t<1, 1, 8, 1, 1>(p, epi, s);
     }
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;

@@ -123,6 +123,10 @@ int main() {
             run<8, 4, 1, 4>("MT1, no operand loads", ch, bias, C);
             run<8, 4, 1, 1>("MT1, W loads nt", ch, bias, C);
             run<8, 4, 1, 3>("MT1, W and X loads nt", ch, bias, C);
+            run<8, 2, 1>("MT1, 8 waves x U2", ch, bias, C);
+            run<8, 1, 1>("MT1, 8 waves x U1", ch, bias, C);
+            run<16, 1, 1>("MT1, 16 waves x U1", ch, bias, C);
+            run<16, 2, 1>("MT1, 16 waves x U2", ch, bias, C);
             run<8, 8, 1>("MT1, 8 waves x U8", ch, bias, C);
             run<16, 4, 1>("MT1, 16 waves x U4", ch, bias, C);
             run<4, 8, 1>("MT1, 4 waves x U8", ch, bias, C);

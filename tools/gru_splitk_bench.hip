@@ -15,7 +15,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 constexpr int M = 64, N = 1024, K = 3072, NB = K / 16, NG = 3;
 
 // x: packed [M/16][NB][64][4]; w: packed [gate][N/16][NB][64][4]; y: packed [M/16][N/16][64][4] (first 1024 of the next x)
-template <int NW, int U, int MT, int S>
+template <int NW, int U, int MT, int S, int IL = 0>
 __global__ __launch_bounds__(NW * 64) void gru_like(const float *__restrict__ x, const float *__restrict__ w,
                                                     float *__restrict__ y, float *__restrict__ part, unsigned *__restrict__ cnt) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][NG][MT][256]
@@ -41,12 +41,13 @@ __global__ __launch_bounds__(NW * 64) void gru_like(const float *__restrict__ x,
             const int k = kb + u < hi ? kb + u : hi - 1;
 #pragma unroll
             for (int q = 0; q < NG; ++q)
-                wv[u][q] = *reinterpret_cast<const f32x4 *>(w + ((((size_t)q * (N / 16) + ntile) * NB + k) * 64 + lane) * 4);
+                wv[u][q] = (IL & 1) ? *reinterpret_cast<const f32x4 *>(w + ((((size_t)ntile * NB + k) * NG + q) * 64 + lane) * 4)      // gates interleaved: 3 KB per k-block
+                              : *reinterpret_cast<const f32x4 *>(w + ((((size_t)q * (N / 16) + ntile) * NB + k) * 64 + lane) * 4);
 #pragma unroll
             for (int j = 0; j < MT; ++j)
                 xv[u][j] = *reinterpret_cast<const f32x4 *>(x + (((size_t)(mg * MT + j) * NB + k) * 64 + lane) * 4);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (!(IL & 2)) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (kb + u < hi) {
@@ -115,15 +116,15 @@ __global__ __launch_bounds__(NW * 64) void gru_like(const float *__restrict__ x,
 
 struct Chain { std::vector<float *> W; float *a, *b, *part; unsigned *cnt; hipStream_t s; hipGraph_t g; hipGraphExec_t ge; };
 
-template <int NW, int U, int MT, int S>
+template <int NW, int U, int MT, int S, int IL = 0>
 void run(const char *name, std::vector<Chain> &ch, int C) {
     const int L = (int)ch[0].W.size(), REPLAY = 20;
     const int lds = NW * NG * MT * 1024;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_like<NW, U, MT, S>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(gru_like<NW, U, MT, S, IL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     for (int c = 0; c < C; ++c) {
         CK(hipStreamBeginCapture(ch[c].s, hipStreamCaptureModeThreadLocal));
         for (int l = 0; l < L; ++l)
-            hipLaunchKernelGGL((gru_like<NW, U, MT, S>), dim3(256 / MT * S), dim3(NW * 64), lds, ch[c].s, (l & 1) ? ch[c].b : ch[c].a,
+            hipLaunchKernelGGL((gru_like<NW, U, MT, S, IL>), dim3(256 / MT * S), dim3(NW * 64), lds, ch[c].s, (l & 1) ? ch[c].b : ch[c].a,
                                ch[c].W[l], (l & 1) ? ch[c].a : ch[c].b, ch[c].part, ch[c].cnt);
         CK(hipStreamEndCapture(ch[c].s, &ch[c].g));
         CK(hipGraphInstantiate(&ch[c].ge, ch[c].g, nullptr, nullptr, 0));
@@ -160,6 +161,14 @@ int main() {
     }
     for (int C = 1; C <= CMAX; ++C) {
         run<16, 2, 1, 1>("A: 16x16 tile, 256 WG x 16 waves, full K", ch, C);
+        run<16, 2, 1, 1, 1>("A with the 3 gates interleaved per k-block", ch, C);
+        run<16, 1, 1, 1, 1>("A interleaved, U=1", ch, C);
+        run<16, 1, 1, 1, 0>("A NOT interleaved, U=1", ch, C);
+        run<16, 1, 1, 1, 3>("A interleaved, U=1, no sched barrier", ch, C);
+        run<16, 2, 1, 1, 3>("A interleaved, U=2, no sched barrier", ch, C);
+        run<8, 2, 1, 1, 1>("A interleaved, 8 waves U=2", ch, C);
+        run<8, 1, 1, 1, 1>("A interleaved, 8 waves U=1", ch, C);
+        run<12, 2, 1, 1, 1>("A interleaved, 12 waves U=2", ch, C);
         run<8, 3, 2, 2>("B: 32x16 tile, split-K 2, 256 WG x 8 waves", ch, C);
         run<8, 2, 4, 4>("B: 64x16 tile, split-K 4, 256 WG x 8 waves", ch, C);
         run<8, 3, 2, 1>("   32x16 tile, full K, 128 WG x 8 waves", ch, C);
