@@ -259,7 +259,7 @@ def main():
                            "kernel": r["kernel"], "mean_launch_us": r["mean_us"],
                            "launches_per_step": r["launches_per_step"],
                            "timer": r["timer"],
-                           "rocprof_avg_us": "5.0 (rocprofv3 --kernel-trace, dispatch-inclusive, --streams 1: profiles/r01_l_kernel_stats_final_1stream.csv)",
+                           "rocprof_avg_us": "5.8 (rocprofv3 --kernel-trace, dispatch-inclusive, --streams 1: profiles/r01_o_kernel_stats_final_1stream.csv)",
                            "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32); algorithmic FLOPs per launch / "
                                    "launch duration measured in situ inside the real schedule.  The layer is not MFMA-limited: "
                                    "each 16x16 output tile pulls 128 KB of operands through its CU's L1, and chains of this "
