@@ -47,6 +47,17 @@ __global__ __launch_bounds__(NW * 64) void gru_like(const float *__restrict__ x,
             for (int j = 0; j < MT; ++j)
                 xv[u][j] = *reinterpret_cast<const f32x4 *>(x + (((size_t)(mg * MT + j) * NB + k) * 64 + lane) * 4);
         }
+        if (IL & 4) {       // finer grain: X and gate 0 first, then one gate at a time (loads of gate q+1 behind the MFMAs of gate q)
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) acc[j][q] = mfma16(xv[0][j][e], wv[0][q][e], acc[j][q]);
+            }
+            continue;
+        }
         if (!(IL & 2)) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -163,6 +174,9 @@ int main() {
         run<16, 2, 1, 1>("A: 16x16 tile, 256 WG x 16 waves, full K", ch, C);
         run<16, 2, 1, 1, 1>("A with the 3 gates interleaved per k-block", ch, C);
         run<16, 1, 1, 1, 1>("A interleaved, U=1", ch, C);
+        run<12, 1, 1, 1, 1>("A interleaved, U=1, 12 waves", ch, C);
+        run<12, 1, 1, 1, 5>("A interleaved, U=1, 12 waves, MFMAs per gate as loads land", ch, C);
+        run<16, 1, 1, 1, 5>("A interleaved, U=1, 16 waves, MFMAs per gate as loads land", ch, C);
         run<16, 1, 1, 1, 0>("A NOT interleaved, U=1", ch, C);
         run<16, 1, 1, 1, 3>("A interleaved, U=1, no sched barrier", ch, C);
         run<16, 2, 1, 1, 3>("A interleaved, U=2, no sched barrier", ch, C);
