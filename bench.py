@@ -27,6 +27,11 @@ import sys
 import tempfile
 import time
 
+# The three-stream schedule relies on the runtime's default of 4 hardware queues per process (one per stream): 3, 5 or 6
+# queues cost 25-60 % of the throughput on this pool (tools/mtw_streams.sh).  Pin the default unless the
+# caller chose otherwise; it must be in the environment before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
