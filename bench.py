@@ -125,7 +125,20 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
 
-    rank, world, device = bdist.init_from_env()
+    # RCCL prints a version banner on STDOUT when its communicator is created; this program's stdout is one JSON line, so
+    # the process group is set up (and its first collective run) with fd 1 pointing at stderr
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        rank, world, device = bdist.init_from_env()
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            torch.cuda.synchronize(device)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     if world != a.gpus and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     assert device.type == "cuda", "bench.py needs an MI355X"
@@ -155,7 +168,10 @@ def main():
     # Steps are independent batches: issue them round-robin on `--streams` HIP streams so that the
     # latency-bound recurrent chain of one batch overlaps the next batch's work (every step still
     # runs the full encode -> decode; all K steps complete inside the timed bracket).
-    streams = [torch.cuda.Stream(device) for _ in range(nstreams)]
+    # ... on streams that really are concurrent: which HIP streams share a hardware queue is not visible through the API
+    # and shifts when an RCCL communicator exists, so the set is measured (bvcodec.dist.concurrent_streams, ~0.3 s)
+    stream_sets = bdist.concurrent_stream_sets(nstreams, device) if nstreams > 1 else [[torch.cuda.Stream(device)]]
+    streams = stream_sets[0]
 
     def run(n):
         last = None
@@ -167,6 +183,24 @@ def main():
             torch.cuda.current_stream(device).wait_stream(st)
         return last
 
+    if len(stream_sets) > 1:
+        # the pair test uses tiny kernels; settle between the candidate sets with the real workload (untimed, before warm-up)
+        # (local steps only: the number of candidate sets may differ between ranks, so no collective in here)
+        def run_local(cand, n):
+            for k in range(n):
+                with torch.cuda.stream(cand[k % len(cand)]):
+                    local_step()
+            torch.cuda.synchronize(device)
+
+        best = None
+        for cand in stream_sets:
+            run_local(cand, len(cand))
+            t_try = time.perf_counter()
+            run_local(cand, 2 * len(cand))
+            t_try = time.perf_counter() - t_try
+            if best is None or t_try < best[0]:
+                best = (t_try, cand)
+        streams = best[1]
     run(max(a.warmup, len(streams)) if a.warmup else 0)
     if use_pg:
         torch.distributed.barrier()

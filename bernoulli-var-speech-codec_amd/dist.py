@@ -72,3 +72,63 @@ def codec_sharded(model, x, bitrate, gather=True):
     if gather and world > 1:
         return gather_batch(codes, x.shape[0]), gather_batch(wav, x.shape[0])
     return codes, wav
+
+
+def concurrent_stream_sets(n, device, candidates=8, chain=200, max_sets=3):
+    """Candidate sets of n torch streams on `device` that really run concurrently, best guess first.
+
+    HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default); which streams share one is
+    not visible through the API and changes with what was created before (an RCCL communicator shifts it).  Two streams on
+    one queue serialise, which costs the three-stream schedule of bench.py a quarter of its throughput.  So: measure.
+    Every pair of `candidates` fresh streams runs two dependent chains of tiny kernels; a pair that takes about as long as
+    two chains back to back shares a queue.  Returns up to `max_sets` sets of n mutually concurrent candidates (sets of
+    streams with fewer conflicts first; the first n candidates if nothing conclusive is found).  Costs ~0.3 s once.
+    A caller with a real workload should time the sets and keep the best (bench.py does)."""
+    import itertools
+    import time
+    if device.type != "cuda":
+        return [[]]
+    if n <= 1:
+        return [[torch.cuda.Stream(device)]]
+    cands = [torch.cuda.Stream(device) for _ in range(max(candidates, n))]
+    bufs = [torch.zeros(256, device=device) for _ in cands]
+
+    def run(idx):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(chain):
+            for i in idx:
+                with torch.cuda.stream(cands[i]):
+                    bufs[i].add_(1.0)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    run([0, 1])                                                   # warm-up (stream creation, kernel load)
+    # issuing 2 x chain launches from one host thread is itself the floor for a concurrent pair: compare pairs with each
+    # other, not with a single chain
+    k = len(cands)
+    t = {}
+    for i in range(k):
+        for j in range(i + 1, k):
+            t[(i, j)] = min(run([i, j]) for _ in range(2))
+    fastest = min(t.values())
+    conflict = {p for p, v in t.items() if v > 1.5 * fastest}
+    score = {i: sum(1 for p in conflict if i in p) for i in range(k)}
+    sets = [c for c in itertools.combinations(range(k), n)
+            if not any(p in conflict for p in itertools.combinations(c, 2))]
+    sets.sort(key=lambda c: (sum(score[i] for i in c), c))
+    if not sets:
+        sets = [tuple(range(n))]
+    # prefer sets that differ from each other (so that timing them tells something)
+    out = [sets[0]]
+    for c in sets[1:]:
+        if len(out) >= max_sets:
+            break
+        if all(len(set(c) & set(o)) < n - 1 for o in out):
+            out.append(c)
+    return [[cands[i] for i in c] for c in out]
+
+
+def concurrent_streams(n, device, candidates=8, chain=200):
+    """The first candidate set of concurrent_stream_sets()."""
+    return concurrent_stream_sets(n, device, candidates, chain, max_sets=1)[0]

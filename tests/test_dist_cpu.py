@@ -81,3 +81,10 @@ def test_shard_range_covers_batch():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_concurrent_stream_sets_without_gpu():
+    """The stream picker is a no-op off the GPU (bench.py only calls it on the MI355X)."""
+    import torch
+    from bvcodec import dist as bdist
+    assert bdist.concurrent_stream_sets(3, torch.device("cpu")) == [[]]

@@ -125,3 +125,21 @@ def test_preprocessing_matches_scipy(fs_in, L):
     refn = ref / np.max(np.abs(ref), axis=1, keepdims=True)
     gotn = preprocess.prepare_speech(torch.from_numpy(x).to(DEV), fs_in).cpu().numpy()
     assert np.abs(gotn - refn).max() < 2e-6 and abs(np.abs(gotn).max() - 1.0) < 1e-6
+
+
+def test_concurrent_stream_picker():
+    """bvcodec.dist.concurrent_stream_sets returns up to three sets of three distinct, usable streams."""
+    from bvcodec import dist as bdist
+    dev = torch.device(DEV)
+    sets = bdist.concurrent_stream_sets(3, dev)
+    assert 1 <= len(sets) <= 3
+    for ss in sets:
+        assert len(ss) == 3 and len({s.cuda_stream for s in ss}) == 3
+        bufs = [torch.zeros(256, device=dev) for _ in ss]
+        for _ in range(20):
+            for s_, b in zip(ss, bufs):
+                with torch.cuda.stream(s_):
+                    b.add_(1.0)
+        torch.cuda.synchronize()
+        assert all(float(b[0]) == 20.0 for b in bufs)
+    assert len(bdist.concurrent_streams(2, dev)) == 2
