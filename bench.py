@@ -27,8 +27,8 @@ import sys
 import tempfile
 import time
 
-# The three-stream schedule relies on the runtime's default of 4 hardware queues per process (one per stream): 3, 5 or 6
-# queues cost 25-60 % of the throughput on this pool (tools/mtw_streams.sh).  Pin the default unless the
+# The four-stream schedule relies on the runtime's default of 4 hardware queues per process (one per stream): 3, 5 or 6
+# queues cost 20-60 % of the throughput on this pool.  Pin the default unless the
 # caller chose otherwise; it must be in the environment before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=SECONDS)
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams the K steps are issued on round-robin (independent batches overlap)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -305,7 +305,7 @@ def main():
                                    "layer shape saturate the chip at 0.37 layers/us = 50 TFLOP/s whatever the tiling "
                                    "(profiles/r01_concurrency_microbench.txt)"}
         # SURVEY.md 8(d) also asks for the whole path against the fp32 peak: algorithmic FLOPs of a step (all families)
-        # over the measured step time of the timed region (the kernels of the three streams overlap, so this is not the
+        # over the measured step time of the timed region (the kernels of the streams overlap, so this is not the
         # sum of the per-launch figures above)
         step_flops = sum(f for f, _ in flops_per_step(conf, B, T).values())
         whole = step_flops / (elapsed / a.steps) / 1e12

@@ -377,9 +377,10 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s, int mtw) {
     if (mtw > m_tiles) mtw = m_tiles >= 4 ? 4 : (m_tiles >= 2 ? 2 : 1);
     if (mtw != 2 && mtw != 4) mtw = 1;
     // How many k-blocks a wave keeps in flight is a trade between one chain and several: chunks of 4 give the shortest
-    // single launch (4.0 us, 4,180 audio-s/s on one stream) but their load bursts crowd out the other streams' kernels;
-    // chunks of 1 (8 waves; 12 waves at K = 2048) take 4.7 us alone (3,860) and give 6,450 instead of 6,100 audio-s/s
-    // with three chains in flight.  Default: throughput; BVC_LATENCY=1 selects the single-chain optimum.
+    // single launch (4.0 us, 4,180 audio-s/s on one stream) but their load bursts crowd out the other streams' kernels.
+    // With FOUR chains in flight: chunks of 4 -> 6,750 audio-s/s, of 2 -> 6,830 (one stream 4,080), of 1 -> 6,850 (3,850);
+    // with three chains the spread was 6,100 / 6,100 / 6,270.  Default: chunks of 2 (1 at K = 2048, 12 waves);
+    // BVC_LATENCY=1 selects the single-chain optimum.
     static const bool latency_mode = getenv("BVC_LATENCY") != nullptr && getenv("BVC_LATENCY")[0] == '1';
     ProbeScope probe((epi == EPI_GRU || epi == EPI_GRU_PART) ? PK_GRU : PK_LINEAR, s);
     if (p.gate_il && epi != EPI_GRU) { set_error("gemm_skinny: gate-interleaved weights are for the GRU launch only"); return BVC_EINVAL; }
@@ -404,7 +405,7 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s, int mtw) {
         if (mtw == 4)      launch_skinny_t<1, 1, 8, 4, 4>(p, epi, s);
         else if (mtw == 2) launch_skinny_t<1, 1, 8, 8, 2>(p, epi, s);
         else if (latency_mode) launch_skinny_t<1, 1, 8, 4, 1>(p, epi, s);
-        else                   launch_skinny_t<1, 1, 8, 1, 1>(p, epi, s);
+        else                   launch_skinny_t<1, 1, 8, 2, 1>(p, epi, s);
     }
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;

@@ -79,7 +79,7 @@ def concurrent_stream_sets(n, device, candidates=8, chain=200, max_sets=3):
 
     HIP multiplexes its streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default); which streams share one is
     not visible through the API and changes with what was created before (an RCCL communicator shifts it).  Two streams on
-    one queue serialise, which costs the three-stream schedule of bench.py a quarter of its throughput.  So: measure.
+    one queue serialise, which costs the multi-stream schedule of bench.py a quarter of its throughput.  So: measure.
     Every pair of `candidates` fresh streams runs two dependent chains of tiny kernels; a pair that takes about as long as
     two chains back to back shares a queue.  Returns up to `max_sets` sets of n mutually concurrent candidates (sets of
     streams with fewer conflicts first; the first n candidates if nothing conclusive is found).  Costs ~0.3 s once.
