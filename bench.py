@@ -44,7 +44,7 @@ BATCH = 64
 SECONDS = 5.0
 BITRATE = 3000
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix = vector peak
-PROBE_NAMES = {1: "gemm_skinny_kernel<1,1,8|12,1,1> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<3,2,12,1,1,gate-interleaved> (GRU cell)",
+PROBE_NAMES = {1: "gemm_skinny_kernel<1,1,8,2,1> / <1,1,12,1,1> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<3,2,12,1,1,gate-interleaved> (GRU cell)",
                3: "amp_pair_kernel / conv_mfma_kernel (BigVGAN convs)", 4: "gemm_batched_(lds_)kernel (phi_x / phi_z and the decoder's phi_z products over all frames)",
                5: "stft_logmel_kernel", 6: "conv_post_kernel"}
 
@@ -298,7 +298,7 @@ def main():
                            "kernel": r["kernel"], "mean_launch_us": r["mean_us"],
                            "launches_per_step": r["launches_per_step"],
                            "timer": r["timer"],
-                           "rocprof_avg_us": "5.8 (rocprofv3 --kernel-trace, dispatch-inclusive, --streams 1: profiles/r01_o_kernel_stats_final_1stream.csv)",
+                           "rocprof_avg_us": "5.2 (rocprofv3 --kernel-trace, dispatch-inclusive, --streams 1: profiles/r01_p_kernel_stats_final_1stream.csv)",
                            "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32); algorithmic FLOPs per launch / "
                                    "launch duration measured in situ inside the real schedule.  The layer is not MFMA-limited: "
                                    "each 16x16 output tile pulls 128 KB of operands through its CU's L1, and chains of this "
