@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libbvcodec_hip.so")
-SOURCES = ["bvcodec_abi.hip", "k_gemm.hip", "k_frontend.hip", "k_vocoder.hip"]
+SOURCES = ["bvcodec_abi.hip", "k_gemm.hip", "k_flow.hip", "k_frontend.hip", "k_vocoder.hip"]
 HEADERS = ["bvc_internal.h", os.path.join("..", "..", "include", "bvcodec.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

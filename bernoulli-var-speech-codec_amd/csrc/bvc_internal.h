@@ -144,6 +144,42 @@ int launch_copy_rows(const float *src, long long lds, float *dst, long long ldd,
 // natural [rows][n] (row stride ld) <-> fragment-packed [rows/16][n/16][64][4]; dir 0: pack, 1: unpack
 int launch_repack_rows(const float *src, float *dst, long long ld_natural, int rows, int n, int dir, hipStream_t s);
 
+// ------------------------------------------------------------------ persistent recurrence (k_flow.hip)
+// All frames of BVRNN.encode / BVRNN.decode in one launch; layers are chained by "poisoned buffer" dataflow
+// (see k_flow.hip).  Activations live in the flow region of the workspace: FlowBuf id, frame parity ->
+// flow + (id * 2 + parity) * slot_bytes, each a fragment-packed [MT16][dim] matrix.
+constexpr unsigned FLOW_POISON = 0xFFFFDEADu;      // a NaN bit pattern no layer may publish as data
+enum FlowEpi { FE_ELU = 0, FE_CODE = 1, FE_MEL = 2, FE_GRU = 3 };
+enum FlowBuf { FB_H = 0, FB_E1, FB_E2, FB_ZC, FB_Q1, FB_Q2, FB_Q3, FB_D1, FB_D2, FB_D3, FB_DN, FB_G1, FB_G2, FB_G3, FB_COUNT };
+struct FlowLin {         // one K-segment of a layer as the persistent kernel sees it (32-/64-bit fields: scalar loads)
+    const float *w;      // packed weights [n/16][k/16][lane][4], offset to the segment's first k-block
+    const float *bias;   // [N] or null
+    int wnb;             // k-blocks per weight row
+    int pad_;
+};
+struct FlowArgs {
+    // layers of the step in dependency order (encode: bvrnn.py:187-206, decode: bvrnn.py:222-227).  enc0h / dec0h: the
+    // halves of enc.0 / dec.0 that multiply h (the other halves are batched over all frames beforehand: part0);
+    // dec0z: the phi_z half of dec.0, used by encode only (there the bias of dec.0 travels in dec0h).
+    FlowLin enc0h, enc1, enc2, pz0, pz1, pz2, dec0h, dec0z, dec1, dec2, dec3, px0, px1, px2;
+    const float *w_hh, *w_ihx, *w_ihz;      // GRU, gate-interleaved [n/16][k/16][gate][lane][4]: W_hh, W_ih[:, :H], W_ih[:, H:]
+    const float *b_ih, *b_hh;
+    int hb, zb, xb;                         // h_dim / 16, z_dim / 16, num_mels / 16
+    float *flow; unsigned slot_bytes;
+    int B, MT, NTG;                         // utterances, utterance groups of 16, feature tiles covered by the grid
+    long long T;
+    const float *part0;                     // (B,T,H) pre-computed half of the first layer (+ its bias)
+    const float *part_gru;                  // decode: (B,T,3H) pre-computed phi_z half of the GRU input gates (+ b_ih)
+    float *codes, *prob; const float *bits; float *all_h; float *mel;
+    const float *mean, *stdv;
+    int var_bit;
+    unsigned *status; unsigned spin_limit;
+};
+int flow_kernels_init();
+int flow_perh(int h_dim);
+int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, hipStream_t s);
+int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s);
+
 // ------------------------------------------------------------------ front-end (k_frontend.hip)
 struct FrontendTables {          // device pointers
     const float *window;         // [1024]

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 
 #include "bvc_internal.h"
 
@@ -88,6 +89,10 @@ struct bvc_model {
     bool fused_amp = true;
     bool precomp_pz = true;     // decode: the phi_z halves of dec.0 and of the GRU input product are batched over all frames
     int mtw = 1;                // 16-row tiles per workgroup in the recurrent kernels (BVC_MTW = 1 | 2 | 4)
+    // persistent recurrence (k_flow.hip): hop tables of encode / decode, resident in device memory
+    bool use_flow = true;       // BVC_RECURRENCE=layers selects the launch-per-layer schedule instead
+    int flow_perh = 0;          // k-blocks per wave of an h_dim-sized segment (0: h_dim not supported by the persistent kernel)
+    unsigned *d_status = nullptr;       // sticky: set by a persistent kernel whose wait timed out
 
     ~bvc_model() {
         for (auto &g : graphs) { (void)hipGraphExecDestroy(g.exec1); (void)hipGraphExecDestroy(g.execN); }
@@ -412,6 +417,9 @@ struct Workspace {
     CallDesc *desc;             // per-call dynamic state read by the captured step kernels
     float *mel, *bits;          // facade-level buffers
     float *part_dec0, *part_gru; // decode: dec.0[:, :H] phi_z + b (B,T,H) and W_ih[:, H:] phi_z + b_ih (B,T,3H), all frames
+    float *flow;                // persistent recurrence: FB_COUNT x 2 fragment-packed [mt16][dmax] activation buffers
+    size_t flow_slot;           // floats per flow buffer
+    FlowArgs *flow_args;        // device copy of the persistent kernel's arguments
     // vocoder
     float *y0, *X, *P, *Q, *U, *XS;
     size_t total;
@@ -443,6 +451,13 @@ void carve(const bvc_model *m, int B, int64_t T, char *base, Workspace *w) {
     w->part_h = take(mt16 * 3 * H);
     w->part_d = take(mt16 * H);
     w->desc = reinterpret_cast<CallDesc *>(take(64));
+    {
+        int dmax = H > c.num_mels ? H : c.num_mels;
+        if (c.z_dim > dmax) dmax = c.z_dim;
+        w->flow_slot = mt16 * (size_t)dmax;
+        w->flow = take((size_t)FB_COUNT * 2 * w->flow_slot);
+        w->flow_args = reinterpret_cast<FlowArgs *>(take((sizeof(FlowArgs) + 3) / 4));
+    }
     w->yn = take(BT * c.num_mels);
     w->pxA = take(mt16 * (size_t)T * H);                       // final phi_x / phi_z: frame-packed
     w->pxB = take(mt16 * (size_t)T * H);                       // intermediates of the batched MLPs: frame-major rows
@@ -791,6 +806,105 @@ int read_state(const Workspace &w, int B, int H, int64_t T, float *d_hT, hipStre
     return launch_repack_rows(src, d_hT, H, B, H, 1, s);
 }
 
+// ---- persistent recurrence (k_flow.hip): hop tables and launch -----------------------------------------
+// Is the model laid out for the persistent kernel?  (h_dim a multiple of 128 up to 1024 or below 128; narrow z / mel layers)
+int build_flow(bvc_model *m) {
+    const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
+    m->flow_perh = flow_perh(H);
+    if (Z > 128 || X > 128) m->flow_perh = 0;
+    if (!m->flow_perh) return BVC_OK;
+    void *st = nullptr;
+    BVC_HIP_TRY(hipMalloc(&st, 64));
+    m->allocs.push_back(st);
+    BVC_HIP_TRY(hipMemset(st, 0, 64));
+    m->d_status = static_cast<unsigned *>(st);
+    return flow_kernels_init();
+}
+
+inline FlowLin flin(const Linear &l, size_t kb_offset = 0, bool with_bias = true) {
+    FlowLin f;
+    f.w = l.wp + kb_offset * 256; f.bias = with_bias ? l.b : nullptr; f.wnb = l.in / 16; f.pad_ = 0;
+    return f;
+}
+
+// The layers of one frame (encode: bvrnn.py:187-206, decode: bvrnn.py:222-227).  Halves of a concatenated input that do
+// not depend on the frame's own chain - phi_x(y_t) in enc.0, phi_z(z_t) in dec.0 and in the GRU's input gates when the
+// codes are known - are batched over all frames beforehand and enter as addends (part0 / part_gru).
+void flow_layers(const bvc_model *m, bool encode, FlowArgs *a) {
+    const int hb = m->cfg.h_dim / 16;
+    a->enc0h = flin(m->enc[0], hb, false);            // enc.0[:, H:] h  (+ part0 = enc.0[:, :H] phi_x + b)
+    a->enc1 = flin(m->enc[1]);
+    a->enc2 = flin(m->enc[2]);
+    a->pz0 = flin(m->phi_z[0]);
+    a->pz1 = flin(m->phi_z[1]);
+    a->pz2 = flin(m->phi_z[2]);
+    a->dec0h = flin(m->dec[0], hb, encode);           // dec.0[:, H:] h; decode: + part0 = dec.0[:, :H] phi_z + b
+    a->dec0z = flin(m->dec[0], 0, false);             // dec.0[:, :H] phi_z (encode)
+    a->dec1 = flin(m->dec[1]);
+    a->dec2 = flin(m->dec[2]);
+    a->dec3 = flin(m->dec[3]);
+    a->px0 = flin(m->phi_x[0]);
+    a->px1 = flin(m->phi_x[1]);
+    a->px2 = flin(m->phi_x[2]);
+    a->w_hh = m->w_hh_il;
+    a->w_ihx = m->w_ih_il;
+    a->w_ihz = m->w_ih_il + (size_t)hb * 3 * 256;
+    a->b_ih = m->b_ih; a->b_hh = m->b_hh;
+    a->hb = hb; a->zb = m->cfg.z_dim / 16; a->xb = m->cfg.num_mels / 16;
+}
+
+inline bool flow_usable(const bvc_model *m, int B) { return m->use_flow && m->flow_perh > 0 && (B + 15) / 16 <= 4; }
+
+inline float *flow_buf(const Workspace &w, int id, int parity) { return w.flow + (size_t)(id * 2 + parity) * w.flow_slot; }
+
+// The persistent kernel needs all its workgroups resident at once (they wait for each other), so launches from
+// different streams are serialised through one event: at most one is in flight per process and device.
+std::mutex g_flow_mu;
+hipEvent_t g_flow_ev[16] = {};
+bool g_flow_ev_used[16] = {};
+
+// All T frames of BVRNN.encode (encode = true) or BVRNN.decode in one launch.  w.part_dec0 (and w.part_gru for decode)
+// must hold the pre-computed halves; h0 may be null (zero state).
+int run_flow(const bvc_model *m, const Workspace &w, bool encode, const float *d_h0, int B, int64_t T, const float *d_bits,
+             float *d_codes, float *d_prob, float *d_all_h, float *d_mel, float *d_hT, hipStream_t s) {
+    const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
+    const int mt16 = ((B + 15) / 16) * 16;
+    int rc;
+    if ((rc = launch_fill_u32(reinterpret_cast<unsigned *>(w.flow), FLOW_POISON, (long long)FB_COUNT * 2 * (long long)w.flow_slot, s))) return rc;
+    float *h0p = flow_buf(w, FB_H, 0);
+    if ((rc = launch_fill(h0p, 0.0f, (long long)mt16 * H, s))) return rc;
+    if (d_h0 && (rc = launch_repack_rows(d_h0, h0p, H, B, H, 0, s))) return rc;
+    if (d_all_h && (rc = launch_repack_rows(h0p, d_all_h, (long long)T * H, B, H, 1, s))) return rc;     // all_h[:, 0] = h0
+    FlowArgs a;
+    memset(&a, 0, sizeof(a));
+    flow_layers(m, encode, &a);
+    a.flow = w.flow;
+    a.slot_bytes = (unsigned)(w.flow_slot * sizeof(float));
+    a.B = B; a.MT = mt16 / 16; a.T = T;
+    a.NTG = (H > X ? (H > Z ? H : Z) : (X > Z ? X : Z)) / 16;
+    a.part0 = w.part_dec0;
+    a.part_gru = encode ? nullptr : w.part_gru;
+    a.codes = d_codes; a.prob = d_prob; a.bits = d_bits; a.all_h = d_all_h; a.mel = d_mel;
+    a.mean = m->mean_mel; a.stdv = m->std_mel;
+    a.var_bit = m->cfg.var_bit;
+    a.status = m->d_status;
+    a.spin_limit = 4000000u;                   // > 1 s of polling: only a workgroup that never became resident gets there
+    {
+        std::lock_guard<std::mutex> lk(g_flow_mu);
+        int dev = 0;
+        BVC_HIP_TRY(hipGetDevice(&dev));
+        dev &= 15;
+        if (!g_flow_ev[dev]) BVC_HIP_TRY(hipEventCreateWithFlags(&g_flow_ev[dev], hipEventDisableTiming));
+        if (g_flow_ev_used[dev]) BVC_HIP_TRY(hipStreamWaitEvent(s, g_flow_ev[dev], 0));
+        ProbeScope probe(PK_LINEAR, s);
+        if ((rc = launch_flow(a, w.flow_args, m->flow_perh, encode, s))) return rc;
+        BVC_HIP_TRY(hipEventRecord(g_flow_ev[dev], s));
+        g_flow_ev_used[dev] = true;
+    }
+    if (d_hT && (rc = launch_repack_rows(flow_buf(w, FB_H, (int)(T & 1)), d_hT, H, B, H, 1, s))) return rc;
+    return BVC_OK;
+}
+
 // Three-layer ELU MLP over ALL frames (phi_x at bvrnn.py:178, phi_z at bvrnn.py:223): in (B*T rows, utterance-major)
 // -> pxA, one fragment-packed [mt16][H] matrix per frame.  (Re-ordering the rows frame-major in the first layer, so
 // that the last one writes whole 1 KiB blocks - GO_FRAME_MAJOR_ROWS / GO_PACKED_FRAMES - measured 0.3 ms per step
@@ -815,6 +929,15 @@ int run_encode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     if (m->cfg.var_bit && !d_bits) { set_error("bits per frame required when var_bit=1"); return BVC_EINVAL; }
     // y = (y - mean) / std ; phi_x over all frames (bvrnn.py:173-178)
     if ((rc = launch_normalize_rows(d_mel, m->mean_mel, m->std_mel, BT, X, w.yn, s))) return rc;
+    if (flow_usable(m, B)) {
+        // ... and so is the phi_x half of enc.0 (bvrnn.py:189): part = enc.0[:, :H] phi_x(y_t) + b, all frames at once
+        const int iBT = (int)BT;
+        if ((rc = launch_gemm_batched(w.yn, X, m->phi_x[0].w, X, m->phi_x[0].b, iBT, H, X, 1, w.pxC, H, s))) return rc;
+        if ((rc = launch_gemm_batched(w.pxC, H, m->phi_x[1].w, H, m->phi_x[1].b, iBT, H, H, 1, w.pxB, H, s))) return rc;
+        if ((rc = launch_gemm_batched(w.pxB, H, m->phi_x[2].w, H, m->phi_x[2].b, iBT, H, H, 1, w.pxC, H, s))) return rc;
+        if ((rc = launch_gemm_batched(w.pxC, H, m->enc[0].w, 2 * H, m->enc[0].b, iBT, H, H, 0, w.part_dec0, H, s))) return rc;
+        return run_flow(m, w, true, d_h0, B, T, d_bits, d_codes, d_prob, d_all_h, nullptr, d_hT, s);
+    }
     if ((rc = batched_mlp3(m, w, m->phi_x, w.yn, X, B, T, s))) return rc;
     if ((rc = init_state(w, d_h0, B, H, s))) return rc;
     if (d_all_h && (rc = launch_repack_rows(w.hbuf, d_all_h, (long long)T * H, B, H, 1, s))) return rc;
@@ -836,7 +959,8 @@ int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     // phi_z depends on the codes only: all frames at once, outside the recurrence (bvrnn.py:223)
     CallDesc d;
     memset(&d, 0, sizeof(d));
-    const bool pre = m->precomp_pz && T >= PRECOMP_MIN_FRAMES;
+    const bool flow = flow_usable(m, B);
+    const bool pre = flow || (m->precomp_pz && T >= PRECOMP_MIN_FRAMES);
     const int kind = pre ? STEP_DECODE_PRE : STEP_DECODE;
     if (pre) {
         // ... and so do the phi_z halves of dec.0 (bvrnn.py:224) and of the GRU's input product (bvrnn.py:227): two more
@@ -848,6 +972,7 @@ int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
         if ((rc = launch_gemm_batched(w.pxC, H, m->dec[0].w, 2 * H, m->dec[0].b, BT, H, H, 0, w.part_dec0, H, s))) return rc;
         if ((rc = launch_gemm_batched(w.pxC, H, m->w_ih_nat + H, 2 * H, m->b_ih, BT, 3 * H, H, 0, w.part_gru, 3 * H, s))) return rc;
         d.p[DS_PARTD] = w.part_dec0; d.p[DS_PARTG] = w.part_gru;
+        if (flow) return run_flow(m, w, false, d_h0, B, T, nullptr, nullptr, nullptr, nullptr, d_mel, d_hT, s);
     } else {
         if ((rc = batched_mlp3(m, w, m->phi_z, d_codes, Z, B, T, s))) return rc;
         d.p[DS_PZ] = w.pxA;
@@ -1179,6 +1304,11 @@ int bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t n
     }
     if ((rc = build_frontend(m.get(), tm))) return rc;
     if ((rc = build_bvrnn(m.get(), tm))) return rc;
+    {
+        const char *rr = getenv("BVC_RECURRENCE");
+        m->use_flow = !(rr && strcmp(rr, "layers") == 0) && !m->side_branch;
+    }
+    if ((rc = build_flow(m.get()))) return rc;
     if ((rc = build_vocoder(m.get(), tm))) return rc;
     BVC_HIP_TRY(hipDeviceSynchronize());
     *out = m.release();
@@ -1365,6 +1495,23 @@ int bvc_vocoder_stream_push(bvc_vocoder_stream *st, const float *d_mel, int32_t 
 #ifdef BVC_PHASE_PROBE
 int bvc_phase_probe_read(unsigned long long *out, int reset) { return bvc::phase_probe_read(out, reset); }
 #endif
+
+int bvc_model_status(const bvc_model *m, uint32_t *code) {
+    if (!m) { set_error("null model"); return BVC_EINVAL; }
+    unsigned v = 0;
+    if (m->d_status) {
+        BVC_HIP_TRY(hipDeviceSynchronize());
+        BVC_HIP_TRY(hipMemcpy(&v, m->d_status, sizeof(v), hipMemcpyDeviceToHost));
+        if (v) BVC_HIP_TRY(hipMemset(m->d_status, 0, sizeof(v)));
+    }
+    if (code) *code = v;
+    if (v) {
+        set_error("a persistent recurrence kernel gave up waiting (frame %u, layer %u): its results are invalid",
+                  (v & 0x7FFFFFFFu) >> 4, (v & 15u));
+        return BVC_ETIMEOUT;
+    }
+    return BVC_OK;
+}
 
 int bvc_probe_begin(int32_t kind, int32_t sample_every, int32_t max_samples) {
     if (kind <= PK_NONE || kind > PK_POST || sample_every < 1 || max_samples < 1) {

@@ -1,0 +1,481 @@
+// Persistent BVRNN recurrence for gfx950: ALL frames of BVRNN.encode / BVRNN.decode (bvrnn.py:186-206,
+// 222-227) in ONE kernel launch.
+//
+// One workgroup (8 waves) owns one 16x16 output tile (16 utterances x 16 features) of EVERY layer of the
+// step, for all frames; the 64 feature tiles of an utterance group form a chain of all-to-all hand-offs
+// (a layer needs the whole output of the previous one), the utterance groups are independent chains.
+// There is no grid barrier and no flag: the hand-off is "poisoned buffer" dataflow.
+//   * every activation buffer exists twice (frame parity) and starts filled with a NaN sentinel;
+//   * a producer stores its 1 KiB output block write-through (sc1) and re-arms its block of the other
+//     parity with the sentinel (its readers finished a frame ago);
+//   * a consumer wave watches the last dword of each producer block it needs (one sc1 load per poll),
+//     then fetches the blocks with sc1 loads (they bypass the non-coherent L1) and verifies that no
+//     dword is the sentinel before it multiplies.  A value equal to the sentinel is never published.
+// K is split over the 8 waves, partial tiles are summed in fixed order through LDS, wave 0 applies the
+// layer's epilogue (bias, ELU, sigmoid/round/bit-mask, mel normalisation, GRU cell).  The MFMA computes
+// Y^T = W X^T (A = weight fragment, B = activation fragment) so that a lane's four results are four
+// consecutive features of one utterance: exactly the 16-byte granule of the next layer's operand block.
+// The next layer's first weight blocks are requested before the wait, so they travel meanwhile.
+// Every wait is bounded: a wave that waits too long records it in the model's status word and stops
+// waiting for good (results are then garbage, the kernel still ends) - bvc_model_status() reports it.
+//
+// Measured form of the hand-off: MI355X_MICROARCH.md (valid forms: sc1 stores, sc1 loads, data-tagged
+// granules), tools/persist_bench.hip (3.3-3.8 us per 1024x1024 layer against 4.25 launch-per-layer).
+#include "bvc_internal.h"
+
+namespace bvc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int AUX_SC1 = 16;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : expf(v) - 1.0f; }
+__device__ __forceinline__ float sigmoid1(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+struct FlowWg {
+    __amdgpu_buffer_rsrc_t rs;       // the flow region
+    int lane, wave, mtile, ntile;
+    unsigned spin_limit;
+    unsigned *status;
+};
+
+__device__ __forceinline__ bool is_poison4(const u32x4 v) {
+    return v[0] == FLOW_POISON || v[1] == FLOW_POISON || v[2] == FLOW_POISON || v[3] == FLOW_POISON;
+}
+
+// Operand blocks [kb0, kb0 + PER) of utterance group g.mtile from the flow buffer at byte offset `buf`
+// (nbdim blocks per utterance group), waiting for their producers.
+template <int PER>
+__device__ __forceinline__ void flow_fetch(const FlowWg &g, unsigned buf, int nbdim, int kb0, u32x4 (&xr)[PER],
+                                           bool &give_up, unsigned code) {
+    // uniform part of every address in the scalar offset, lane part in one shared VGPR
+    const unsigned base = __builtin_amdgcn_readfirstlane(buf + (unsigned)(g.mtile * nbdim + kb0) * 1024u);
+    const unsigned fl = (unsigned)(g.lane < PER ? g.lane : PER - 1) * 1024u + 63u * 16u + 12u;
+    const unsigned vl = (unsigned)g.lane * 16u;
+    unsigned spins = 0;
+    while (!give_up) {
+        const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(g.rs, fl, base, AUX_SC1);
+        if (!__any(t == FLOW_POISON)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > g.spin_limit) {
+            give_up = true;
+            if (g.lane == 0) atomicExch(g.status, code);
+        }
+    }
+    bool again;
+    do {                                                   // a flag can be visible before the rest of its block
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            xr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, vl, base + (unsigned)u * 1024u, AUX_SC1));
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) bad |= is_poison4(xr[u]);
+        again = __any(bad) && !give_up;
+        if (again && ++spins > g.spin_limit) {
+            give_up = true;
+            if (g.lane == 0) atomicExch(g.status, code);
+        }
+    } while (again);
+}
+
+// Lane's view of a run of weight blocks: a wave-uniform byte pointer (kept in SGPRs, re-derived every frame so that the
+// compiler does not hoist fourteen layers' worth of per-lane addresses out of the frame loop) plus lane * 16.
+typedef const char __attribute__((address_space(1))) *GPtr;        // global (not flat) loads
+__device__ __forceinline__ GPtr uniform_ptr(const float *w, size_t block) {
+    unsigned long long p = reinterpret_cast<unsigned long long>(w) + (block << 10);
+    asm volatile("" : "+s"(p));
+    return (GPtr)p;
+}
+__device__ __forceinline__ f32x4 wload(GPtr ub, unsigned lane16, int blk) {
+    return *reinterpret_cast<const f32x4 __attribute__((address_space(1))) *>(ub + lane16 + (unsigned)blk * 1024u);
+}
+
+// acc += W[ntile rows][segment] . X[segment]   for this wave's share of the segment's k-blocks
+template <int PER>
+__device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int wnb, int nb, unsigned buf, bool w_ready,
+                                            f32x4 (&wv)[PER], f32x4 &acc, bool &give_up, unsigned code) {
+    const int kb0 = g.wave * PER;
+    if (PER == 1 && g.wave >= nb) return;                  // wave-uniform: fewer k-blocks than waves
+    if (!w_ready) {
+        const GPtr ub = uniform_ptr(w, (size_t)g.ntile * wnb + kb0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) wv[u] = wload(ub, (unsigned)g.lane * 16u, u);
+    }
+    u32x4 xr[PER];
+    flow_fetch<PER>(g, buf, nb, kb0, xr, give_up, code);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const f32x4 xv = __builtin_bit_cast(f32x4, xr[u]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma16(wv[u][e], xv[e], acc);
+    }
+}
+
+// the three gates of a GRU segment; weights gate-interleaved [n/16][k/16][gate][lane][4]
+template <int PER>
+__device__ __forceinline__ void gru_segment(const FlowWg &g, const float *w, int wnb, int nb, unsigned buf, f32x4 (&acc)[3],
+                                            bool &give_up, unsigned code) {
+    const int kb0 = g.wave * PER;
+    if (PER == 1 && g.wave >= nb) return;
+    constexpr int HALF = PER >= 4 ? PER / 4 : 1;       // weight blocks requested per round (x 3 gates)
+    const GPtr ub = uniform_ptr(w, ((size_t)g.ntile * wnb + kb0) * 3);
+    const unsigned l16 = (unsigned)g.lane * 16u;
+    f32x4 w3[HALF][3];
+#pragma unroll
+    for (int u = 0; u < HALF; ++u)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) w3[u][q] = wload(ub, l16, u * 3 + q);
+    u32x4 xr[PER];
+    flow_fetch<PER>(g, buf, nb, kb0, xr, give_up, code);
+#pragma unroll
+    for (int h0 = 0; h0 < PER; h0 += HALF) {
+        if (h0 > 0) {
+#pragma unroll
+            for (int u = 0; u < HALF; ++u)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) w3[u][q] = wload(ub, l16, (h0 + u) * 3 + q);
+        }
+#pragma unroll
+        for (int u = 0; u < HALF; ++u) {
+            const f32x4 xv = __builtin_bit_cast(f32x4, xr[h0 + u]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[q] = mfma16(w3[u][q][e], xv[e], acc[q]);
+        }
+    }
+}
+
+__device__ __forceinline__ u32x4 publishable(f32x4 o, bool rowok) {
+    u32x4 b = __builtin_bit_cast(u32x4, o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (b[j] == FLOW_POISON) b[j] = 0x7FC00000u;       // never publish the sentinel as data
+        if (!rowok) b[j] = 0u;                             // padding rows of the last utterance group stay zero
+    }
+    return b;
+}
+
+// per-workgroup state of the frame loop
+// The kernel arguments are read through a constant-address-space pointer that is made opaque once per frame: their
+// fields then come in by scalar loads where they are used, instead of ~100 SGPRs being filled (and spilled) up front.
+typedef const FlowArgs __attribute__((address_space(4))) *FlowArgsC;
+
+template <typename P>
+__device__ __forceinline__ FlowLin L(const P &l) {        // member-wise copy out of the constant address space
+    FlowLin r;
+    r.w = l.w; r.bias = l.bias; r.wnb = l.wnb; r.pad_ = 0;
+    return r;
+}
+
+struct FlowCtx {
+    FlowWg g;
+    FlowArgsC a;
+    float *red_lin, *red_gru;
+    unsigned par;            // frame parity
+    long long t, fr;         // frame; (utterance, frame) index of this lane's row
+    int row;
+    bool rowok, give_up;
+    unsigned hopctr;
+};
+
+// One layer: y = epi( sum_s W_s . x_s + bias [+ addend] ).  PER k-blocks per wave and segment (compile time), one or
+// two segments (the one whose input is produced last comes last), PRE_IN: wv already holds segment 0's weights,
+// PRE_OUT: request `nxt`'s weights (PERN blocks per wave) into wn before the reduction.
+template <int PER, int EPI, bool TWO, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN>
+__device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin l0, int src0, const FlowLin l1, int src1,
+                                           int nb, int ntiles, int out, f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN]) {
+    const FlowWg &g = c.g;
+    const auto &a = *c.a;
+    if (g.ntile >= ntiles) {                               // uniform per workgroup (layers narrower than h_dim)
+        if (PRE_OUT) {
+#pragma unroll
+            for (int u = 0; u < PERN; ++u) wn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};      // defined on every path: no value lives across the layer
+        }
+        return;
+    }
+    const int lane = g.lane, wave = g.wave;
+    const unsigned code = (unsigned)((c.t << 4) | (unsigned)hopid) | 0x80000000u;
+    const int n0 = g.ntile * 16 + (lane >> 4) * 4;
+    const unsigned ytile = (unsigned)((g.mtile * ntiles + g.ntile) * 1024 + lane * 16);
+    // ---- epilogue operands of wave 0, requested up front
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, add4 = {0.f, 0.f, 0.f, 0.f}, mean4 = {0.f, 0.f, 0.f, 0.f}, std4 = {1.f, 1.f, 1.f, 1.f};
+    float bitsv = 0.0f;
+    if (wave == 0) {
+        if (l0.bias) bias4 = *reinterpret_cast<const f32x4 *>(l0.bias + n0);
+        if (ADD && c.rowok) add4 = *reinterpret_cast<const f32x4 *>(a.part0 + c.fr * (ntiles * 16) + n0);
+        if (EPI == FE_CODE && a.var_bit && c.rowok) bitsv = a.bits[c.fr];
+        if (EPI == FE_MEL) {
+            mean4 = *reinterpret_cast<const f32x4 *>(a.mean + n0);
+            std4 = *reinterpret_cast<const f32x4 *>(a.stdv + n0);
+        }
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code);
+    if (TWO) lin_segment<PER>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code);
+    if (PRE_OUT) {                                         // the next layer's weights travel during the reduction and the wait
+        const GPtr ub = uniform_ptr(nxt.w, (size_t)g.ntile * nxt.wnb + wave * PERN);
+#pragma unroll
+        for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
+    }
+    float *r = c.red_lin + (c.hopctr & 1u) * 2048;
+    ++c.hopctr;
+    *reinterpret_cast<f32x4 *>(r + (wave * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(r + lane * 4);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) v += *reinterpret_cast<const f32x4 *>(r + (w * 64 + lane) * 4);
+        v += bias4;
+        f32x4 o;
+        if (EPI == FE_ELU) {
+            if (ADD) v += add4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = elu1(v[j]);
+        } else if (EPI == FE_CODE) {                       // bvrnn.py:189-194
+            f32x4 pr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pr[j] = sigmoid1(v[j]);
+                float z = rintf(pr[j]);                    // round half to even (torch.round)
+                if (a.var_bit) z = (bitsv > (float)(n0 + j)) ? z : 0.5f;
+                o[j] = z;
+            }
+            if (c.rowok) {
+                *reinterpret_cast<f32x4 *>(a.codes + c.fr * (ntiles * 16) + n0) = o;
+                if (a.prob) *reinterpret_cast<f32x4 *>(a.prob + c.fr * (ntiles * 16) + n0) = pr;
+            }
+        } else {                                           // FE_MEL, bvrnn.py:202-204
+            if (a.mel && c.rowok) *reinterpret_cast<f32x4 *>(a.mel + c.fr * (ntiles * 16) + n0) = v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean4[j]) / std4[j];
+        }
+        unsigned pv = FLOW_POISON;
+        asm volatile("" : "+v"(pv));                       // re-materialised here (hoisted out of the frame loop it gets spilled)
+        const u32x4 poison4 = {pv, pv, pv, pv};
+        const unsigned ob = (unsigned)(out * 2) * a.slot_bytes;
+        __builtin_amdgcn_raw_buffer_store_b128(publishable(o, c.rowok), g.rs, ob + c.par * a.slot_bytes + ytile, 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, ob + (c.par ^ 1u) * a.slot_bytes + ytile, 0, AUX_SC1);
+    }
+}
+
+// GRU cell (PyTorch gate order r, z, n; bvrnn.py:206,227): gh = W_hh h, gi = W_ih [phi_x_gen ; phi_z]; in decode the
+// phi_z half of gi (+ b_ih) arrives pre-computed (a.part_gru).  Segments in the order their inputs become ready.
+template <int PER, bool ENCODE, int PERN>
+__device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const FlowLin nxt, f32x4 (&wn)[PERN]) {
+    const FlowWg &g = c.g;
+    const auto &a = *c.a;
+    if (g.ntile >= hb) {
+#pragma unroll
+        for (int u = 0; u < PERN; ++u) wn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const int lane = g.lane, wave = g.wave;
+    const unsigned code = (unsigned)((c.t << 4) | (unsigned)hopid) | 0x80000000u;
+    const int n0 = g.ntile * 16 + (lane >> 4) * 4;
+    const unsigned ytile = (unsigned)((g.mtile * hb + g.ntile) * 1024 + lane * 16);
+    const long long H = (long long)hb * 16;
+    const unsigned hbuf = (unsigned)(FB_H * 2) * a.slot_bytes;
+    f32x4 gi[3], gh[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { gi[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; gh[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    gru_segment<PER>(g, a.w_hh, hb, hb, hbuf + c.par * a.slot_bytes, gh, c.give_up, code);
+    if (ENCODE) gru_segment<PER>(g, a.w_ihz, 2 * hb, hb, (unsigned)(FB_Q3 * 2 + c.par) * a.slot_bytes, gi, c.give_up, code);
+    gru_segment<PER>(g, a.w_ihx, 2 * hb, hb, (unsigned)(FB_G3 * 2 + c.par) * a.slot_bytes, gi, c.give_up, code);
+    // epilogue operands of wave 0: requested now, they arrive while the other waves reach the barrier
+    f32x4 bi[3], bh[3], pg[3];
+    u32x4 hprev = {0u, 0u, 0u, 0u};
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            bi[q] = ENCODE ? *reinterpret_cast<const f32x4 *>(a.b_ih + q * H + n0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            bh[q] = *reinterpret_cast<const f32x4 *>(a.b_hh + q * H + n0);
+            pg[q] = (!ENCODE && c.rowok) ? *reinterpret_cast<const f32x4 *>(a.part_gru + c.fr * 3 * H + q * H + n0)
+                                         : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // this workgroup's own block of h(t): written by itself a frame ago (or the initial state)
+        hprev = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, hbuf + c.par * a.slot_bytes + ytile, 0, AUX_SC1));
+    }
+    {   // the first layer of the next frame (after the last frame a harmless extra request: no value is carried across)
+        const GPtr ub = uniform_ptr(nxt.w, (size_t)g.ntile * nxt.wnb + wave * PERN);
+#pragma unroll
+        for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
+    }
+    float *red_gru = c.red_gru;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        *reinterpret_cast<f32x4 *>(red_gru + ((wave * 6 + q) * 64 + lane) * 4) = gi[q];
+        *reinterpret_cast<f32x4 *>(red_gru + ((wave * 6 + 3 + q) * 64 + lane) * 4) = gh[q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        f32x4 v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            v[k] = *reinterpret_cast<const f32x4 *>(red_gru + (k * 64 + lane) * 4);
+#pragma unroll
+            for (int w = 1; w < 8; ++w) v[k] += *reinterpret_cast<const f32x4 *>(red_gru + ((w * 6 + k) * 64 + lane) * 4);
+        }
+        const f32x4 hp4 = __builtin_bit_cast(f32x4, hprev);
+        f32x4 hn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gi_r = (v[0][j] + bi[0][j]) + pg[0][j], gi_z = (v[1][j] + bi[1][j]) + pg[1][j];
+            const float gi_n = (v[2][j] + bi[2][j]) + pg[2][j];
+            const float gh_r = v[3][j] + bh[0][j], gh_z = v[4][j] + bh[1][j], gh_n = v[5][j] + bh[2][j];
+            const float rg = sigmoid1(gh_r + gi_r);
+            const float zg = sigmoid1(gh_z + gi_z);
+            const float ng = tanhf(gi_n + rg * gh_n);
+            hn[j] = (hp4[j] - ng) * zg + ng;
+        }
+        if (a.all_h && c.rowok && c.t + 1 < a.T) *reinterpret_cast<f32x4 *>(a.all_h + (c.fr + 1) * H + n0) = hn;   // all_h[:, t+1], bvrnn.py:205
+        unsigned pv = FLOW_POISON;
+        asm volatile("" : "+v"(pv));
+        const u32x4 poison4 = {pv, pv, pv, pv};
+        __builtin_amdgcn_raw_buffer_store_b128(publishable(hn, c.rowok), g.rs, hbuf + (c.par ^ 1u) * a.slot_bytes + ytile, 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, hbuf + c.par * a.slot_bytes + ytile, 0, AUX_SC1);
+    }
+    // red_gru is single-buffered: its next writers are a whole step (and many barriers) away
+}
+
+}  // namespace
+
+// PERH: k-blocks per wave of an h_dim-sized operand (h_dim = 128 * PERH, or h_dim <= 128 for PERH = 1: then a wave owns at
+// most one k-block); the z_dim- and num_mels-sized operands (<= 128) always have one k-block per wave.
+template <int PERH, bool ENCODE>
+__global__ __launch_bounds__(512) void bvrnn_flow_kernel(const FlowArgs *a0) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][8][256] layer partials | [8][6][256] GRU partials
+    const int tid = threadIdx.x;
+    FlowCtx c;
+    FlowArgsC ap = (FlowArgsC)(unsigned long long)a0;      // device-resident copy of the arguments (flow_set_args_kernel)
+    c.a = ap;
+    c.red_lin = lds;
+    c.red_gru = lds + 2 * 8 * 256;
+    c.g.lane = tid & 63;
+    c.g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int MT = ap->MT;
+    c.g.ntile = (slot / MT) * 8 + xcd;                    // the utterance groups of a feature tile share an XCD (weights cross the fabric once)
+    c.g.mtile = slot % MT;
+    if (c.g.ntile >= ap->NTG) return;                      // grid is rounded up to a multiple of 8 feature tiles
+    c.g.rs = __builtin_amdgcn_make_buffer_rsrc(ap->flow, 0, (int)(FB_COUNT * 2u * ap->slot_bytes), 0x00020000);
+    c.g.spin_limit = ap->spin_limit;
+    c.g.status = ap->status;
+    c.row = c.g.mtile * 16 + (c.g.lane & 15);
+    c.rowok = c.row < ap->B;
+    c.give_up = false;
+    c.hopctr = 0;
+    const int hb = ap->hb, zb = ap->zb, xb = ap->xb;
+    const long long T = ap->T;
+    const bool hfull = c.g.ntile < hb;                     // this workgroup owns a tile of the h_dim-wide layers
+    f32x4 wa[PERH], wb[PERH], w1[1];
+    {
+        const FlowLin first = ENCODE ? L(ap->enc0h) : L(ap->dec0h);
+        const GPtr ub = uniform_ptr(first.w, hfull ? (size_t)c.g.ntile * first.wnb + c.g.wave * PERH : 0);
+#pragma unroll
+        for (int u = 0; u < PERH; ++u) wa[u] = wload(ub, (unsigned)c.g.lane * 16u, u);
+    }
+    for (long long t = 0; t < T; ++t) {
+        asm volatile("" : "+s"(ap));                       // see FlowArgsC
+        c.a = ap;
+        const auto &a = *ap;
+        c.t = t;
+        c.par = (unsigned)(t & 1);
+        c.fr = (long long)c.row * T + t;
+        if (ENCODE) {
+            //         PER   epilogue  two    add    pre_in pre_out
+            flow_layer<PERH, FE_ELU,  false, true,  true,  true,  PERH>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb);
+            flow_layer<PERH, FE_ELU,  false, false, true,  false, PERH>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa);
+            flow_layer<PERH, FE_CODE, false, false, false, false, PERH>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb);
+            flow_layer<1,    FE_ELU,  false, false, false, true,  PERH>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa);
+            flow_layer<PERH, FE_ELU,  false, false, true,  true,  PERH>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb);
+            flow_layer<PERH, FE_ELU,  false, false, true,  true,  PERH>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa);
+            flow_layer<PERH, FE_ELU,  true,  false, true,  true,  PERH>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb);
+        } else {
+            flow_layer<PERH, FE_ELU,  false, true,  true,  true,  PERH>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb);
+        }
+        flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa);
+        flow_layer<PERH, FE_ELU, false, false, true,  false, PERH>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb);
+        flow_layer<PERH, FE_MEL, false, false, false, false, PERH>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb);
+        flow_layer<1,    FE_ELU, false, false, false, true,  PERH>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa);
+        flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb);
+        flow_layer<PERH, FE_ELU, false, false, true,  false, PERH>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa);
+        flow_gru<PERH, ENCODE, PERH>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa);
+    }
+}
+
+__global__ void fill_u32_kernel(unsigned *p, unsigned v, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s) {
+    if (n <= 0) return BVC_OK;
+    const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(grid), dim3(256), 0, s, p, v, n);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
+constexpr size_t FLOW_LDS = (2 * 8 * 256 + 8 * 6 * 256) * sizeof(float);      // 64 KiB
+
+template <int PERH, bool ENC>
+static int flow_attr() {
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<PERH, ENC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS));
+    return BVC_OK;
+}
+
+int flow_kernels_init() {
+    int rc;
+    if ((rc = flow_attr<1, true>()) || (rc = flow_attr<1, false>()) || (rc = flow_attr<2, true>()) || (rc = flow_attr<2, false>()) ||
+        (rc = flow_attr<4, true>()) || (rc = flow_attr<4, false>()) || (rc = flow_attr<8, true>()) || (rc = flow_attr<8, false>())) return rc;
+    return BVC_OK;
+}
+
+// k-blocks per wave of an h_dim-sized segment, or 0 if this h_dim is not laid out for the persistent kernel
+int flow_perh(int h_dim) {
+    if (h_dim % 16) return 0;
+    if (h_dim == 128) return 1;
+    if (h_dim == 256) return 2;
+    if (h_dim == 512) return 4;
+    if (h_dim == 1024) return 8;
+    if (h_dim < 128) return 1;
+    return 0;
+}
+
+__global__ void flow_set_args_kernel(FlowArgs *dst, FlowArgs v) {
+    const unsigned *src = reinterpret_cast<const unsigned *>(&v);
+    unsigned *d = reinterpret_cast<unsigned *>(dst);
+    for (unsigned i = threadIdx.x; i < sizeof(FlowArgs) / 4; i += blockDim.x) d[i] = src[i];
+}
+
+template <int PERH>
+static void flow_launch_t(const FlowArgs *d_a, bool encode, int grid, hipStream_t s) {
+    if (encode) hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, true>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
+    else        hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, false>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
+}
+
+// d_args: device memory for a copy of `a` (read by the kernel through the scalar cache); it must stay untouched until the
+// launch has finished.
+int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, hipStream_t s) {
+    static_assert(sizeof(FlowArgs) % 4 == 0, "FlowArgs is copied in dwords");
+    hipLaunchKernelGGL(flow_set_args_kernel, dim3(1), dim3(256), 0, s, d_args, a);
+    const FlowArgs *d_a = d_args;
+    const int grid = ((a.NTG + 7) / 8) * 8 * a.MT;
+    switch (perh) {
+        case 1: flow_launch_t<1>(d_a, encode, grid, s); break;
+        case 2: flow_launch_t<2>(d_a, encode, grid, s); break;
+        case 4: flow_launch_t<4>(d_a, encode, grid, s); break;
+        case 8: flow_launch_t<8>(d_a, encode, grid, s); break;
+        default: set_error("launch_flow: unsupported blocks per wave %d", perh); return BVC_EINVAL;
+    }
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
+}  // namespace bvc

@@ -96,6 +96,13 @@ class _Engine:
     def stream(self):
         return _abi.current_stream(self.device)
 
+    def check_status(self):
+        """Synchronises the device and raises if a persistent recurrence kernel of this model ever gave up waiting
+        (its results were then invalid); see bvc_model_status in include/bvcodec.h."""
+        code = ctypes.c_uint32(0)
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.bvc_model_status(self.handle, ctypes.byref(code)))
+
     def num_frames(self, L):
         return int(self.lib.bvc_num_frames(self.handle, L))
 
@@ -122,6 +129,11 @@ class _OnDevice(nn.Module):
         if probe.device.type == "cuda":
             self._device = _as_device(probe.device)
         return super()._apply(fn, *a, **k)
+
+    def check_status(self):
+        """Device-synchronising health check of the engines this module has created (bvc_model_status)."""
+        for eng in list(self._engines.values()):
+            eng.check_status()
 
     def engine(self, like=None):
         dev = self._device

@@ -11,11 +11,20 @@
  *  - plain C, no torch/HIP types: `stream` is a hipStream_t passed as void* (NULL = default stream);
  *  - every pointer named d_* is DEVICE memory owned by the caller, contiguous float32;
  *    every pointer named h_* is HOST memory;
- *  - all compute entry points are asynchronous on `stream`, never allocate, never synchronise
- *    (safe inside hipStreamBeginCapture), and use only the caller-provided workspace;
+ *  - the compute entry points (bvc_stft_logmel, bvc_bvrnn_*, bvc_bigvgan, bvc_encode, bvc_decode,
+ *    bvc_vocoder_stream_push, bvc_pack/unpack_codes, bvc_resample_poly, bvc_peak_normalize) are
+ *    asynchronous on `stream` and use only the caller-provided workspace.  They do not allocate or
+ *    synchronise, with these exceptions: the FIRST call per process creates one HIP event, and - only
+ *    with BVC_RECURRENCE=layers, the launch-per-layer schedule - the first call per (batch,
+ *    workspace) captures and instantiates a hipGraph on a stream of the library's own.  Call once
+ *    before capturing these entry points into a graph of your own;
+ *  - bvc_model_status, bvc_probe_end, bvc_kprobe_* and the bvc_test_* helpers synchronise the device;
  *  - return value: 0 = BVC_OK, negative = error code; bvc_last_error() gives the text
  *    (thread-local); no C++ exception crosses the boundary;
- *  - one in-flight call per (model, workspace); models are immutable after creation.
+ *  - one in-flight call per (model, workspace): calls on different streams with different
+ *    workspaces may overlap (the recurrence kernels of overlapping calls run one after the other,
+ *    everything else concurrently); models are immutable after creation; the library is not
+ *    re-entrant on ONE model from several host threads at once.
  */
 #ifndef BVCODEC_H
 #define BVCODEC_H
@@ -35,7 +44,8 @@ enum {
     BVC_ENOMEM = -2,      /* workspace too small or device allocation failed */
     BVC_EHIP = -3,        /* HIP runtime error (see bvc_last_error) */
     BVC_EMISSING = -4,    /* a required weight tensor is missing or has the wrong size */
-    BVC_ENODEVICE = -5    /* no gfx950 device visible */
+    BVC_ENODEVICE = -5,   /* no gfx950 device visible */
+    BVC_ETIMEOUT = -6     /* a persistent recurrence kernel gave up waiting for its peers (bvc_model_status) */
 };
 
 /* Static description of the codec; mirrors the TOML keys the reference facade reads
@@ -81,6 +91,13 @@ const char  *bvc_last_error(void);
 int  bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t n_tensors,
                       bvc_model **out);
 void bvc_model_destroy(bvc_model *m);
+
+/* The recurrence of BVRNN.encode / BVRNN.decode (bvrnn.py:186-206, 222-227) runs as ONE persistent kernel
+ * whose workgroups hand activations to each other; every wait in it is bounded.  If a wait ever timed out
+ * (a workgroup that never became resident), the kernel ends with invalid results and records it in the
+ * model: this call synchronises the device, returns BVC_ETIMEOUT and the recorded code (frame << 4 | layer)
+ * and clears it; BVC_OK and 0 otherwise. */
+int bvc_model_status(const bvc_model *m, uint32_t *code);
 
 /* Frames for L samples: floor(L / hop)  (torch.stft center=False after the reflect pad,
  * meldataset.py:72-85).  Returns < 0 when L <= win - hop (reflect pad impossible). */

@@ -28,3 +28,14 @@ def conf_var():
 def conf_fix():
     from bvcodec import config
     return config.load_config(config.DEFAULT_CONFIG_64BIT)
+
+
+@pytest.fixture(autouse=True)
+def _recurrence_health(request):
+    """After every GPU test: no persistent recurrence kernel may have given up waiting (bvc_model_status)."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import gpu_common
+    for model, *_ in list(gpu_common._CACHE.values()):
+        model.check_status()
