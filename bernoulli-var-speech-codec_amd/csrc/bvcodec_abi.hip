@@ -888,7 +888,16 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, const float *d
     a.mean = m->mean_mel; a.stdv = m->std_mel;
     a.var_bit = m->cfg.var_bit;
     a.status = m->d_status;
+    { static const bool hot = getenv("BVC_FLOW_HOTW") != nullptr; a.dbg_hot_w = hot ? 1 : 0; }
     a.spin_limit = 4000000u;                   // > 1 s of polling: only a workgroup that never became resident gets there
+    if (g_kprobe.enabled) {                    // bench instrumentation: per-layer entry / exit stamps of workgroup 0
+        const int nodes = encode ? 14 : 8;
+        const size_t need = (size_t)2 * T * nodes;
+        if (need > g_kprobe.capacity) { set_error("kprobe buffer too small for T=%lld", (long long)T); return BVC_EINVAL; }
+        BVC_HIP_TRY(hipMemsetAsync(g_kprobe.dev, 0, need * sizeof(unsigned long long), s));
+        g_kprobe.T = T; g_kprobe.nodes = nodes;
+        a.probe = g_kprobe.dev; a.probe_nodes = nodes; a.probe_first = encode ? 1 : 7;
+    }
     {
         std::lock_guard<std::mutex> lk(g_flow_mu);
         int dev = 0;

@@ -41,6 +41,7 @@ __device__ __forceinline__ float sigmoid1(float v) { return 1.0f / (1.0f + expf(
 struct FlowWg {
     __amdgpu_buffer_rsrc_t rs;       // the flow region
     int lane, wave, mtile, ntile;
+    int wmul;                        // 1 (0 in the hot-weights timing experiment)
     unsigned spin_limit;
     unsigned *status;
 };
@@ -51,16 +52,22 @@ __device__ __forceinline__ bool is_poison4(const u32x4 v) {
 
 // Operand blocks [kb0, kb0 + PER) of utterance group g.mtile from the flow buffer at byte offset `buf`
 // (nbdim blocks per utterance group), waiting for their producers.
+// (Tried and dropped: a self-tuned delay followed by fetching the blocks directly, without the flag poll - 0.4 us per
+// layer faster in tools/persist_bench.hip, no faster in the real step, whose layers are bound by the operand stream.)
+struct FlowSrc { unsigned base, vl; };     // scalar byte offset of this wave's first operand block, lane offset
+
+// Waits until the producers of blocks [kb0, kb0 + PER) of utterance group g.mtile have published them (one dword per
+// producer block and poll).  A flag can be visible before the rest of its block: the consumer still verifies what it fetches.
 template <int PER>
-__device__ __forceinline__ void flow_fetch(const FlowWg &g, unsigned buf, int nbdim, int kb0, u32x4 (&xr)[PER],
-                                           bool &give_up, unsigned code) {
+__device__ __forceinline__ FlowSrc flow_wait(const FlowWg &g, unsigned buf, int nbdim, int kb0, bool &give_up, unsigned code,
+                                             unsigned &spins) {
+    FlowSrc s;
     // uniform part of every address in the scalar offset, lane part in one shared VGPR
-    const unsigned base = __builtin_amdgcn_readfirstlane(buf + (unsigned)(g.mtile * nbdim + kb0) * 1024u);
+    s.base = __builtin_amdgcn_readfirstlane(buf + (unsigned)(g.mtile * nbdim + kb0) * 1024u);
+    s.vl = (unsigned)g.lane * 16u;
     const unsigned fl = (unsigned)(g.lane < PER ? g.lane : PER - 1) * 1024u + 63u * 16u + 12u;
-    const unsigned vl = (unsigned)g.lane * 16u;
-    unsigned spins = 0;
     while (!give_up) {
-        const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(g.rs, fl, base, AUX_SC1);
+        const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(g.rs, fl, s.base, AUX_SC1);
         if (!__any(t == FLOW_POISON)) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > g.spin_limit) {
@@ -68,20 +75,14 @@ __device__ __forceinline__ void flow_fetch(const FlowWg &g, unsigned buf, int nb
             if (g.lane == 0) atomicExch(g.status, code);
         }
     }
-    bool again;
-    do {                                                   // a flag can be visible before the rest of its block
+    return s;
+}
+
+template <int PER>
+__device__ __forceinline__ void flow_issue(const FlowWg &g, const FlowSrc &s, u32x4 (&xr)[PER]) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u)
-            xr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, vl, base + (unsigned)u * 1024u, AUX_SC1));
-        bool bad = false;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) bad |= is_poison4(xr[u]);
-        again = __any(bad) && !give_up;
-        if (again && ++spins > g.spin_limit) {
-            give_up = true;
-            if (g.lane == 0) atomicExch(g.status, code);
-        }
-    } while (again);
+    for (int u = 0; u < PER; ++u)
+        xr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, s.vl, s.base + (unsigned)u * 1024u, AUX_SC1));
 }
 
 // Lane's view of a run of weight blocks: a wave-uniform byte pointer (kept in SGPRs, re-derived every frame so that the
@@ -103,53 +104,86 @@ __device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int
     const int kb0 = g.wave * PER;
     if (PER == 1 && g.wave >= nb) return;                  // wave-uniform: fewer k-blocks than waves
     if (!w_ready) {
-        const GPtr ub = uniform_ptr(w, (size_t)g.ntile * wnb + kb0);
+        const GPtr ub = uniform_ptr(w, ((size_t)g.ntile * wnb + kb0) * g.wmul);
 #pragma unroll
         for (int u = 0; u < PER; ++u) wv[u] = wload(ub, (unsigned)g.lane * 16u, u);
     }
-    u32x4 xr[PER];
-    flow_fetch<PER>(g, buf, nb, kb0, xr, give_up, code);
+    unsigned spins = 0;
+    const FlowSrc src = flow_wait<PER>(g, buf, nb, kb0, give_up, code, spins);
+    const f32x4 acc_in = acc;
+    bool again;
+    do {
+        // The blocks are multiplied as they arrive (the loads return in order); whether one of them still held the
+        // sentinel is only known at the end: then the products are thrown away and everything is fetched again.
+        u32x4 xr[PER];
+        flow_issue<PER>(g, src, xr);
+        f32x4 a2 = acc_in;
+        bool bad = false;
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const f32x4 xv = __builtin_bit_cast(f32x4, xr[u]);
+        for (int u = 0; u < PER; ++u) {
+            bad |= is_poison4(xr[u]);
+            const f32x4 xv = __builtin_bit_cast(f32x4, xr[u]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = mfma16(wv[u][e], xv[e], acc);
-    }
+            for (int e = 0; e < 4; ++e) a2 = mfma16(wv[u][e], xv[e], a2);
+        }
+        again = __any(bad) && !give_up;
+        if (!again) acc = a2;
+        else if (++spins > g.spin_limit) {
+            give_up = true;
+            if (g.lane == 0) atomicExch(g.status, code);
+        }
+    } while (again);
 }
 
-// the three gates of a GRU segment; weights gate-interleaved [n/16][k/16][gate][lane][4]
-template <int PER>
-__device__ __forceinline__ void gru_segment(const FlowWg &g, const float *w, int wnb, int nb, unsigned buf, f32x4 (&acc)[3],
-                                            bool &give_up, unsigned code) {
-    const int kb0 = g.wave * PER;
-    if (PER == 1 && g.wave >= nb) return;
-    constexpr int HALF = PER >= 4 ? PER / 4 : 1;       // weight blocks requested per round (x 3 gates)
-    const GPtr ub = uniform_ptr(w, ((size_t)g.ntile * wnb + kb0) * 3);
-    const unsigned l16 = (unsigned)g.lane * 16u;
-    f32x4 w3[HALF][3];
+// One round of a GRU segment: HALF k-blocks x 3 gates of weights (gate-interleaved [n/16][k/16][gate][lane][4]).
+template <int HALF>
+__device__ __forceinline__ void gru_issue_w(GPtr ub, unsigned l16, int h0, f32x4 (&w3)[HALF][3]) {
 #pragma unroll
     for (int u = 0; u < HALF; ++u)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) w3[u][q] = wload(ub, l16, u * 3 + q);
-    u32x4 xr[PER];
-    flow_fetch<PER>(g, buf, nb, kb0, xr, give_up, code);
+        for (int q = 0; q < 3; ++q) w3[u][q] = wload(ub, l16, (h0 + u) * 3 + q);
+}
+template <int PER, int HALF>
+__device__ __forceinline__ void gru_round(const f32x4 (&w3)[HALF][3], const u32x4 (&xr)[PER], int h0, f32x4 (&acc)[3]) {
 #pragma unroll
-    for (int h0 = 0; h0 < PER; h0 += HALF) {
-        if (h0 > 0) {
+    for (int u = 0; u < HALF; ++u) {
+        const f32x4 xv = __builtin_bit_cast(f32x4, xr[h0 + u]);
 #pragma unroll
-            for (int u = 0; u < HALF; ++u)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) w3[u][q] = wload(ub, l16, (h0 + u) * 3 + q);
-        }
-#pragma unroll
-        for (int u = 0; u < HALF; ++u) {
-            const f32x4 xv = __builtin_bit_cast(f32x4, xr[h0 + u]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) acc[q] = mfma16(w3[u][q][e], xv[e], acc[q]);
-        }
+            for (int q = 0; q < 3; ++q) acc[q] = mfma16(w3[u][q][e], xv[e], acc[q]);
     }
+}
+
+// operand blocks of an input this wave has already fetched and verified earlier in the frame (h at the first layer, phi_z
+// at dec.0): complete, and not re-armed before the next frame, so neither a flag wait nor a check is needed
+template <int PER>
+__device__ __forceinline__ void gru_issue_known(const FlowWg &g, unsigned buf, int nb, u32x4 (&xr)[PER]) {
+    const int kb0 = g.wave * PER;
+    FlowSrc s;
+    s.base = __builtin_amdgcn_readfirstlane(buf + (unsigned)(g.mtile * nb + kb0) * 1024u);
+    s.vl = (unsigned)g.lane * 16u;
+    flow_issue<PER>(g, s, xr);
+}
+
+// operand blocks of the input that is being produced right now: wait, fetch, verify
+template <int PER>
+__device__ __forceinline__ void gru_fetch_fresh(const FlowWg &g, unsigned buf, int nb, u32x4 (&xr)[PER], bool &give_up, unsigned code) {
+    const int kb0 = g.wave * PER;
+    unsigned spins = 0;
+    const FlowSrc src = flow_wait<PER>(g, buf, nb, kb0, give_up, code, spins);
+    bool again;
+    do {
+        flow_issue<PER>(g, src, xr);
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) bad |= is_poison4(xr[u]);
+        again = __any(bad) && !give_up;
+        if (again && ++spins > g.spin_limit) {
+            give_up = true;
+            if (g.lane == 0) atomicExch(g.status, code);
+        }
+    } while (again);
 }
 
 __device__ __forceinline__ u32x4 publishable(f32x4 o, bool rowok) {
@@ -182,13 +216,20 @@ struct FlowCtx {
     long long t, fr;         // frame; (utterance, frame) index of this lane's row
     int row;
     bool rowok, give_up;
+    bool probe;              // this lane records layer entry / exit times (bench instrumentation)
     unsigned hopctr;
 };
+
+__device__ __forceinline__ void flow_stamp(const FlowCtx &c, int hopid, int which) {
+    if (!c.probe) return;
+    const auto &a = *c.a;
+    a.probe[((long long)which * a.T + c.t) * a.probe_nodes + (hopid - a.probe_first)] = __builtin_amdgcn_s_memrealtime();
+}
 
 // One layer: y = epi( sum_s W_s . x_s + bias [+ addend] ).  PER k-blocks per wave and segment (compile time), one or
 // two segments (the one whose input is produced last comes last), PRE_IN: wv already holds segment 0's weights,
 // PRE_OUT: request `nxt`'s weights (PERN blocks per wave) into wn before the reduction.
-template <int PER, int EPI, bool TWO, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN>
+template <int PER, int EPI, bool TWO, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H = false>
 __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin l0, int src0, const FlowLin l1, int src1,
                                            int nb, int ntiles, int out, f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN]) {
     const FlowWg &g = c.g;
@@ -204,6 +245,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
     const unsigned code = (unsigned)((c.t << 4) | (unsigned)hopid) | 0x80000000u;
     const int n0 = g.ntile * 16 + (lane >> 4) * 4;
     const unsigned ytile = (unsigned)((g.mtile * ntiles + g.ntile) * 1024 + lane * 16);
+    flow_stamp(c, hopid, 0);
     // ---- epilogue operands of wave 0, requested up front
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, add4 = {0.f, 0.f, 0.f, 0.f}, mean4 = {0.f, 0.f, 0.f, 0.f}, std4 = {1.f, 1.f, 1.f, 1.f};
     float bitsv = 0.0f;
@@ -220,7 +262,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
     lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code);
     if (TWO) lin_segment<PER>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code);
     if (PRE_OUT) {                                         // the next layer's weights travel during the reduction and the wait
-        const GPtr ub = uniform_ptr(nxt.w, (size_t)g.ntile * nxt.wnb + wave * PERN);
+        const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
     }
@@ -262,6 +304,10 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
         const unsigned ob = (unsigned)(out * 2) * a.slot_bytes;
         __builtin_amdgcn_raw_buffer_store_b128(publishable(o, c.rowok), g.rs, ob + c.par * a.slot_bytes + ytile, 0, AUX_SC1);
         __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, ob + (c.par ^ 1u) * a.slot_bytes + ytile, 0, AUX_SC1);
+        // The slot that will receive h(t+1) still holds h(t-1).  This layer's input was produced by workgroups that had all
+        // consumed h(t), i.e. had all finished frame t-1: nobody reads h(t-1) any more (same tile shape as this layer's).
+        if (REARM_H) __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, (unsigned)(FB_H * 2 + (c.par ^ 1u)) * a.slot_bytes + ytile, 0, AUX_SC1);
+        flow_stamp(c, hopid, 1);
     }
 }
 
@@ -282,12 +328,42 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
     const unsigned ytile = (unsigned)((g.mtile * hb + g.ntile) * 1024 + lane * 16);
     const long long H = (long long)hb * 16;
     const unsigned hbuf = (unsigned)(FB_H * 2) * a.slot_bytes;
+    flow_stamp(c, hopid, 0);
     f32x4 gi[3], gh[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) { gi[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; gh[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    gru_segment<PER>(g, a.w_hh, hb, hb, hbuf + c.par * a.slot_bytes, gh, c.give_up, code);
-    if (ENCODE) gru_segment<PER>(g, a.w_ihz, 2 * hb, hb, (unsigned)(FB_Q3 * 2 + c.par) * a.slot_bytes, gi, c.give_up, code);
-    gru_segment<PER>(g, a.w_ihx, 2 * hb, hb, (unsigned)(FB_G3 * 2 + c.par) * a.slot_bytes, gi, c.give_up, code);
+    // h(t) and (encode) phi_z(z_t) are complete and were verified by this very wave earlier in the frame: their blocks are
+    // requested at once and multiplied while phi_x(d_t), the input produced last, is still on its way
+    // The weights stream through two register sets: the request for round i+1 is issued before round i is multiplied.
+    if (!(PER == 1 && wave >= hb)) {                       // (wave-uniform) a wave without a k-block of its own contributes zeros
+        constexpr int HALF = PER >= 4 ? PER / 4 : 1;       // k-blocks per round
+        constexpr int RPS = PER / HALF;                    // rounds per segment
+        constexpr int NSEG = ENCODE ? 3 : 2;
+        constexpr int NR = NSEG * RPS;
+        const int kb0 = wave * PER;
+        const unsigned l16 = (unsigned)lane * 16u;
+        const GPtr uh = uniform_ptr(a.w_hh, ((size_t)g.ntile * hb + kb0) * 3 * g.wmul);
+        const GPtr uz = uniform_ptr(a.w_ihz, ((size_t)g.ntile * 2 * hb + kb0) * 3 * g.wmul);
+        const GPtr ux = uniform_ptr(a.w_ihx, ((size_t)g.ntile * 2 * hb + kb0) * 3 * g.wmul);
+        u32x4 xa[PER], xb[PER];
+        f32x4 wr[2][HALF][3];
+        gru_issue_w<HALF>(uh, l16, 0, wr[0]);
+        gru_issue_known<PER>(g, hbuf + c.par * a.slot_bytes, hb, xa);
+        if (ENCODE) gru_issue_known<PER>(g, (unsigned)(FB_Q3 * 2 + c.par) * a.slot_bytes, hb, xb);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int sg = i / RPS, h0 = (i % RPS) * HALF;
+            if (i + 1 < NR) {
+                const int sn = (i + 1) / RPS, hn0 = ((i + 1) % RPS) * HALF;
+                gru_issue_w<HALF>(sn == 0 ? uh : ((ENCODE && sn == 1) ? uz : ux), l16, hn0, wr[(i + 1) & 1]);
+            }
+            if (i == (NSEG - 1) * RPS)                     // the last segment's input, phi_x(d_t): wait, fetch, verify
+                gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * a.slot_bytes, hb, xa, c.give_up, code);
+            if (sg == 0)                gru_round<PER, HALF>(wr[i & 1], xa, h0, gh);
+            else if (ENCODE && sg == 1) gru_round<PER, HALF>(wr[i & 1], xb, h0, gi);
+            else                        gru_round<PER, HALF>(wr[i & 1], xa, h0, gi);
+        }
+    }
     // epilogue operands of wave 0: requested now, they arrive while the other waves reach the barrier
     f32x4 bi[3], bh[3], pg[3];
     u32x4 hprev = {0u, 0u, 0u, 0u};
@@ -303,7 +379,7 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         hprev = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, hbuf + c.par * a.slot_bytes + ytile, 0, AUX_SC1));
     }
     {   // the first layer of the next frame (after the last frame a harmless extra request: no value is carried across)
-        const GPtr ub = uniform_ptr(nxt.w, (size_t)g.ntile * nxt.wnb + wave * PERN);
+        const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
     }
@@ -335,11 +411,10 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
             hn[j] = (hp4[j] - ng) * zg + ng;
         }
         if (a.all_h && c.rowok && c.t + 1 < a.T) *reinterpret_cast<f32x4 *>(a.all_h + (c.fr + 1) * H + n0) = hn;   // all_h[:, t+1], bvrnn.py:205
-        unsigned pv = FLOW_POISON;
-        asm volatile("" : "+v"(pv));
-        const u32x4 poison4 = {pv, pv, pv, pv};
+        // h(t)'s slot is NOT re-armed here: other workgroups may still be reading h(t) in their own GRU layer.  It is re-armed
+        // by the second layer of frame t+1 (REARM_H), whose inputs prove that every workgroup has left frame t.
         __builtin_amdgcn_raw_buffer_store_b128(publishable(hn, c.rowok), g.rs, hbuf + (c.par ^ 1u) * a.slot_bytes + ytile, 0, AUX_SC1);
-        __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, hbuf + c.par * a.slot_bytes + ytile, 0, AUX_SC1);
+        flow_stamp(c, hopid, 1);
     }
     // red_gru is single-buffered: its next writers are a whole step (and many barriers) away
 }
@@ -366,10 +441,12 @@ __global__ __launch_bounds__(512) void bvrnn_flow_kernel(const FlowArgs *a0) {
     if (c.g.ntile >= ap->NTG) return;                      // grid is rounded up to a multiple of 8 feature tiles
     c.g.rs = __builtin_amdgcn_make_buffer_rsrc(ap->flow, 0, (int)(FB_COUNT * 2u * ap->slot_bytes), 0x00020000);
     c.g.spin_limit = ap->spin_limit;
+    c.g.wmul = ap->dbg_hot_w ? 0 : 1;
     c.g.status = ap->status;
     c.row = c.g.mtile * 16 + (c.g.lane & 15);
     c.rowok = c.row < ap->B;
     c.give_up = false;
+    c.probe = ap->probe != nullptr && bid == 0 && tid == 0;
     c.hopctr = 0;
     const int hb = ap->hb, zb = ap->zb, xb = ap->xb;
     const long long T = ap->T;
@@ -391,7 +468,7 @@ __global__ __launch_bounds__(512) void bvrnn_flow_kernel(const FlowArgs *a0) {
         if (ENCODE) {
             //         PER   epilogue  two    add    pre_in pre_out
             flow_layer<PERH, FE_ELU,  false, true,  true,  true,  PERH>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb);
-            flow_layer<PERH, FE_ELU,  false, false, true,  false, PERH>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa);
+            flow_layer<PERH, FE_ELU,  false, false, true,  false, PERH, true>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa);
             flow_layer<PERH, FE_CODE, false, false, false, false, PERH>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb);
             flow_layer<1,    FE_ELU,  false, false, false, true,  PERH>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa);
             flow_layer<PERH, FE_ELU,  false, false, true,  true,  PERH>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb);
@@ -400,7 +477,8 @@ __global__ __launch_bounds__(512) void bvrnn_flow_kernel(const FlowArgs *a0) {
         } else {
             flow_layer<PERH, FE_ELU,  false, true,  true,  true,  PERH>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb);
         }
-        flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa);
+        if (ENCODE) flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa);
+        else        flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH, true>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa);
         flow_layer<PERH, FE_ELU, false, false, true,  false, PERH>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb);
         flow_layer<PERH, FE_MEL, false, false, false, false, PERH>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb);
         flow_layer<1,    FE_ELU, false, false, false, true,  PERH>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa);
