@@ -68,6 +68,7 @@ SIGNATURES = {
                                        ctypes.POINTER(_i32)]),
     "bvc_test_linear": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "bvc_test_linear_batched": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "bvc_test_snakebeta": (ctypes.c_int, [_vp, _i64, _f, _f, _vp, _vp]),
     "bvc_test_vocoder_tap": (ctypes.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, ctypes.POINTER(_i64), _vp, _sz, _vp]),
 }
 

@@ -227,6 +227,7 @@ struct ConvWindow { long long in_bs, out_bs, row_begin, t_origin; };
 // in (B, Lin, cin) channels-last; out (B, Lout, cout).  Output row r reads input rows
 // r - (ks-1)*dil ... r  (rows outside [0,Lin) are zero).  res/acc have the layout of out.
 int conv_kernels_init();
+int launch_snakebeta_test(const float *x, long long n, float a, float ib, float *y, hipStream_t s);
 int launch_conv_mfma(const ConvLayer &c, const float *in, long long Lin, float *out, long long Lout,
                      int B, int epi, const float *res, const float *acc, float divisor, hipStream_t s,
                      const ConvWindow *win = nullptr);

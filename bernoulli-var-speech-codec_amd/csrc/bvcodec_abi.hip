@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <list>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -80,8 +81,11 @@ struct bvc_model {
     const float *post_a = nullptr, *post_ib = nullptr, *post_w = nullptr, *post_b = nullptr;
     int post_c = 0, post_ks = 7;
     // captured recurrent steps (hipGraph), keyed by (kind, batch, workspace)
-    struct StepGraph { int kind; int B; void *ws; void *probe; hipGraphExec_t exec1, execN; };
-    mutable std::vector<StepGraph> graphs;
+    // (launch-per-layer schedule only) most recently used first; `idle` is recorded behind the entry's last replay, so an
+    // entry is only destroyed once the GPU is done with it
+    struct StepGraph { int kind; int B; void *ws; void *probe; hipGraphExec_t exec1, execN; hipEvent_t idle; };
+    mutable std::list<StepGraph> graphs;
+    mutable std::mutex graph_mu;
     mutable hipStream_t cap_stream = nullptr, side_stream = nullptr;
     mutable std::vector<hipEvent_t> cap_events;
     bool side_branch = false;   // measured SLOWER on MI355X (cross-branch graph dependencies + no spare L2->CU bandwidth): opt-in
@@ -95,7 +99,7 @@ struct bvc_model {
     unsigned *d_status = nullptr;       // sticky: set by a persistent kernel whose wait timed out
 
     ~bvc_model() {
-        for (auto &g : graphs) { (void)hipGraphExecDestroy(g.exec1); (void)hipGraphExecDestroy(g.execN); }
+        for (auto &g : graphs) { (void)hipGraphExecDestroy(g.exec1); (void)hipGraphExecDestroy(g.execN); if (g.idle) (void)hipEventDestroy(g.idle); }
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         if (side_stream) (void)hipStreamDestroy(side_stream);
         for (auto e : cap_events) (void)hipEventDestroy(e);
@@ -710,12 +714,18 @@ int launch_steps(const bvc_model *m, const std::vector<StepNode> &plan, const Wo
 
 constexpr int GRAPH_STEPS = 8;
 
-// Returns the cached graph pair for (kind, B, workspace), capturing it on first use.
+constexpr size_t GRAPH_CACHE_ENTRIES = 64;      // (kind, batch, workspace) triples kept per model; least recently used goes first
+
+// Returns the cached graph pair for (kind, B, workspace), capturing it on first use.  Caller holds m->graph_mu.
 int get_step_graph(const bvc_model *m, const Workspace &w, void *ws_base, int B, int kind,
-                   const std::vector<StepNode> &plan, const bvc_model::StepGraph **out) {
+                   const std::vector<StepNode> &plan, bvc_model::StepGraph **out) {
     void *probe = g_kprobe.enabled ? (void *)g_kprobe.dev : nullptr;
-    for (const auto &g : m->graphs)
-        if (g.kind == kind && g.B == B && g.ws == ws_base && g.probe == probe) { *out = &g; return BVC_OK; }
+    for (auto it = m->graphs.begin(); it != m->graphs.end(); ++it)
+        if (it->kind == kind && it->B == B && it->ws == ws_base && it->probe == probe) {
+            m->graphs.splice(m->graphs.begin(), m->graphs, it);          // most recently used first
+            *out = &m->graphs.front();
+            return BVC_OK;
+        }
     if (!m->cap_stream) BVC_HIP_TRY(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
     if (!m->side_stream) BVC_HIP_TRY(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
     while ((int)m->cap_events.size() < EV_COUNT) {
@@ -723,7 +733,7 @@ int get_step_graph(const bvc_model *m, const Workspace &w, void *ws_base, int B,
         BVC_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         m->cap_events.push_back(e);
     }
-    bvc_model::StepGraph sg{kind, B, ws_base, probe, nullptr, nullptr};
+    bvc_model::StepGraph sg{kind, B, ws_base, probe, nullptr, nullptr, nullptr};
     for (int which = 0; which < 2; ++which) {
         hipGraph_t graph = nullptr;
         g_capturing = true;
@@ -744,12 +754,15 @@ int get_step_graph(const bvc_model *m, const Workspace &w, void *ws_base, int B,
         BVC_HIP_TRY(hipGraphDestroy(graph));
         (which ? sg.execN : sg.exec1) = ex;
     }
-    if (m->graphs.size() >= 16) {               // bound the cache: drop the oldest
-        (void)hipGraphExecDestroy(m->graphs[0].exec1); (void)hipGraphExecDestroy(m->graphs[0].execN);
-        m->graphs.erase(m->graphs.begin());
+    BVC_HIP_TRY(hipEventCreateWithFlags(&sg.idle, hipEventDisableTiming));
+    while (m->graphs.size() >= GRAPH_CACHE_ENTRIES) {       // bound the cache: the least recently used entry goes, once it is idle
+        bvc_model::StepGraph &old = m->graphs.back();
+        (void)hipEventSynchronize(old.idle);                  // (never recorded: returns at once)
+        (void)hipGraphExecDestroy(old.exec1); (void)hipGraphExecDestroy(old.execN); (void)hipEventDestroy(old.idle);
+        m->graphs.pop_back();
     }
-    m->graphs.push_back(sg);
-    *out = &m->graphs.back();
+    m->graphs.push_front(sg);
+    *out = &m->graphs.front();
     return BVC_OK;
 }
 
@@ -763,7 +776,8 @@ int run_recurrence(const bvc_model *m, const Workspace &w, void *ws_base, int B,
             if ((rc2 = launch_steps(m, plan, w, 1, s, nullptr))) return rc2;
         return BVC_OK;
     }
-    const bvc_model::StepGraph *g = nullptr;
+    std::lock_guard<std::mutex> lk(m->graph_mu);          // cache look-up, replay and the idle mark are one critical section
+    bvc_model::StepGraph *g = nullptr;
     if ((rc = get_step_graph(m, w, ws_base, B, kind, plan, &g))) {
         if (rc != BVC_EHIP) return rc;
         // stream capture unavailable (e.g. the caller is itself capturing): same kernels, launched eagerly
@@ -775,6 +789,7 @@ int run_recurrence(const bvc_model *m, const Workspace &w, void *ws_base, int B,
     int64_t t = 0;
     for (; t + GRAPH_STEPS <= T; t += GRAPH_STEPS) BVC_HIP_TRY(hipGraphLaunch(g->execN, s));
     for (; t < T; ++t) BVC_HIP_TRY(hipGraphLaunch(g->exec1, s));
+    BVC_HIP_TRY(hipEventRecord(g->idle, s));
     return BVC_OK;
 }
 
@@ -1634,6 +1649,13 @@ int bvc_test_linear(const float *d_x, const float *d_w, const float *d_bias, int
 int bvc_test_linear_batched(const float *d_x, const float *d_w, const float *d_bias, int32_t M, int32_t N, int32_t K,
                             int32_t act, float *d_y, void *stream) {
     return launch_gemm_batched(d_x, K, d_w, K, d_bias, M, N, K, act, d_y, N, (hipStream_t)stream);
+}
+
+int bvc_test_snakebeta(const float *d_x, int64_t n, float alpha, float beta, float *d_y, void *stream) {
+    if (!d_x || !d_y || n <= 0) { set_error("bvc_test_snakebeta: bad arguments"); return BVC_EINVAL; }
+    const float a = (float)std::exp((double)alpha);                                  // as make_conv() derives them
+    const float ib = 1.0f / ((float)std::exp((double)beta) + 0.000000001f);
+    return launch_snakebeta_test(d_x, n, a, ib, d_y, (hipStream_t)stream);
 }
 
 int bvc_test_vocoder_tap(const bvc_model *m, const float *d_mel, int32_t B, int64_t T, int32_t which, float *d_out,

@@ -546,6 +546,27 @@ static int allow_big_lds() {
     return BVC_OK;
 }
 
+// test helper: y[i] = SnakeBeta(x[i]) with one (exp(alpha), 1/(exp(beta)+1e-9)) pair, through the same device functions the
+// generator uses (scalar and packed form on alternating elements)
+__global__ void snakebeta_test_kernel(const float *__restrict__ x, long long n, float a, float ib, float *__restrict__ y) {
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += (long long)gridDim.x * blockDim.x * 2) {
+        if (i + 1 < n) {
+            const f32x2 v = snakebeta2((f32x2){x[i], x[i + 1]}, splat2(a), splat2(ib));
+            y[i] = v[0];
+            y[i + 1] = snakebeta(x[i + 1], a, ib) == v[1] ? v[1] : __builtin_nanf("");     // both forms must agree bit for bit
+        } else {
+            y[i] = snakebeta(x[i], a, ib);
+        }
+    }
+}
+
+int launch_snakebeta_test(const float *x, long long n, float a, float ib, float *y, hipStream_t s) {
+    if (n <= 0) return BVC_OK;
+    hipLaunchKernelGGL(snakebeta_test_kernel, dim3(256), dim3(256), 0, s, x, n, a, ib, y);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
 int conv_kernels_init() {
     int rc;
     if ((rc = allow_big_lds<128, 4, 2>())) return rc;

@@ -2,7 +2,8 @@
 
 The reference is single-device; utterances are independent (no cross-batch op at
 bvrnn.py:186-206,222-227 or models.py:207-238), so a batch shards trivially: each rank encodes and
-decodes its contiguous slice with zero communication and ONE RCCL collective gathers the results
+decodes its contiguous slice with zero communication and one RCCL collective per gathered tensor (waveforms;
+optionally the codes too) collects the results
 (``torch.distributed`` backend "nccl" is RCCL on ROCm; over xGMI).  On CPU-only hosts the same code
 runs on gloo, which is how tests/test_dist_cpu.py covers it.
 """
@@ -60,17 +61,24 @@ def gather_batch(local, total=None, out=None):
     return torch.cat([buf[r * nmax: r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
 
 
-def codec_sharded(model, x, bitrate, gather=True):
+def codec_sharded(model, x, bitrate, gather=True, gather_codes=True):
     """encode+decode of the rank's slice of x (B_total, L) and (optionally) the gathered result.
-    Returns (codes, wav) - full batch on every rank when gather=True, local slice otherwise."""
+    Returns (codes, wav) - full batch on every rank when gather=True, local slice otherwise.
+    gather=True issues one collective for the waveforms and, unless gather_codes=False, a second one for the
+    codes (then the returned codes stay the local slice).  Every rank needs at least one utterance: with fewer
+    utterances than ranks ALL ranks raise before any work or collective is issued (an empty rank would
+    otherwise fail alone and leave the others waiting in the gather)."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
+    if x.shape[0] < world:
+        raise ValueError(f"codec_sharded: {x.shape[0]} utterances cannot be sharded over {world} ranks "
+                         "(every rank needs at least one)")
     lo, hi = shard_range(x.shape[0], world, rank)
     xl = x[lo:hi]
     codes = model.encode(xl, bitrate)
     wav = model.decode(codes, x.shape[1])
     if gather and world > 1:
-        return gather_batch(codes, x.shape[0]), gather_batch(wav, x.shape[0])
+        return (gather_batch(codes, x.shape[0]) if gather_codes else codes), gather_batch(wav, x.shape[0])
     return codes, wav
 
 

@@ -21,8 +21,13 @@ from .config import DEFAULT_CONFIG, load_config
 
 _ROOT = os.path.abspath(os.path.dirname(__file__))
 default_config = DEFAULT_CONFIG
-default_chkpt_bvrnn = os.path.join(_ROOT, "chkpts", "bvrnn_var_bitrate_step200000")
-default_chkpt_vocoder = os.path.join(_ROOT, "chkpts", "bigvgan_causal_tiny_ftbvrnn_g_step3500000")
+# The reference resolves its default checkpoints next to its module file (bvrnn_codec_model.py:11-15: ./chkpts/...).
+# Same file names here, looked up in $BVC_CHKPT_DIR if set, else in ./chkpts next to the drop-in shim
+# (bvrnn_codec_model.py at the repository root).  The files themselves are Git-LFS objects of the reference and are
+# not shipped: the constructor names the path it looked at when one is missing.
+_CHKPT_DIR = os.environ.get("BVC_CHKPT_DIR") or os.path.join(os.path.dirname(_ROOT), "chkpts")
+default_chkpt_bvrnn = os.path.join(_CHKPT_DIR, "bvrnn_var_bitrate_step200000")
+default_chkpt_vocoder = os.path.join(_CHKPT_DIR, "bigvgan_causal_tiny_ftbvrnn_g_step3500000")
 
 SCALING = 10 ** (-10 / 20)      # bvrnn_codec_model.py:17
 
@@ -128,6 +133,8 @@ class _OnDevice(nn.Module):
         probe = fn(torch.empty(0))
         if probe.device.type == "cuda":
             self._device = _as_device(probe.device)
+        elif probe.device.type == "cpu":        # .cpu(): no residence of its own; the next call follows its input again
+            self._device = None
         return super()._apply(fn, *a, **k)
 
     def check_status(self):
@@ -281,11 +288,14 @@ class BigVGAN(_OnDevice):
 class BVRNNCodecModel(_OnDevice):
     def __init__(self, config_path=default_config, bvrnn_chkpt_path=default_chkpt_bvrnn,
                  vocoder_chkpt_path=default_chkpt_vocoder):
-        '''
-        config_path: path to the toml config file
-        bvrnn_chkpt_path: path to the checkpoint of the BVRNN model
-        vocoder_chkpt_path: path to the checkpoint of the vocoder model
-        '''
+        """Same three arguments as the reference constructor (bvrnn_codec_model.py:20-42): the TOML file that describes
+        front-end, coder and vocoder, and the two ``torch.save`` dicts holding the coder's ``'vrnn'`` and the vocoder's
+        ``'generator'`` state dict.  Both checkpoints are loaded strictly; nothing touches the GPU until the first call."""
+        for what, path in (("BVRNN", bvrnn_chkpt_path), ("vocoder", vocoder_chkpt_path)):
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"{what} checkpoint not found at '{path}'.  Pass the path explicitly, or place the "
+                                        f"reference's chkpts/ files (Git-LFS objects, not shipped) in '{_CHKPT_DIR}' "
+                                        "(override with BVC_CHKPT_DIR)")
         conf = load_config(config_path)
         vrnn_sd = weights.load_checkpoint(bvrnn_chkpt_path, "vrnn")
         gen_sd = weights.load_checkpoint(vocoder_chkpt_path, "generator")
@@ -318,10 +328,9 @@ class BVRNNCodecModel(_OnDevice):
 
     @torch.no_grad()
     def encode(self, x, bitrate):
-        '''
-        x: input waveform, shape (batch, length)
-        bitrate: target bitrate in bits per second, will be rounded to the nearest valid bitrate
-        '''
+        """Waveforms ``x`` (batch, samples), expected in [-1, 1], to codes (batch, samples // hop, z_dim) with values in
+        {0, 1} and 0.5 at masked positions.  ``bitrate`` [bit/s] selects round(bitrate * hop / fs) leading bits per frame
+        (saturating at z_dim; ignored by fixed-rate configs) - bvrnn_codec_model.py:44-62."""
         eng = self.engine(x)
         out_dev = x.device
         x = _prep(x, eng.device)
@@ -341,10 +350,8 @@ class BVRNNCodecModel(_OnDevice):
 
     @torch.no_grad()
     def decode(self, codes, length):
-        '''
-        codes: latent binary codes, shape (batch, frames, z_dim)
-        length: length of the output waveform
-        '''
+        """Codes (batch, frames, z_dim) back to waveforms (batch, min(length, 256 * frames + 294)): coder decode from a
+        zero state, vocoder, output gain undone - bvrnn_codec_model.py:64-71."""
         eng = self.engine(codes)
         out_dev = codes.device
         codes = _prep(codes, eng.device)
@@ -360,6 +367,7 @@ class BVRNNCodecModel(_OnDevice):
         return wav.to(out_dev)
 
     def forward(self, x, bitrate):
+        """decode(encode(x, bitrate)) trimmed to the input length (bvrnn_codec_model.py:73-76)."""
         length = x.shape[1]
         codes = self.encode(x, bitrate)
         return self.decode(codes, length)

@@ -202,6 +202,10 @@ int bvc_test_vocoder_tap(const bvc_model *m, const float *d_mel, int32_t B, int6
                          float *d_out, int64_t *out_numel_per_batch, void *d_ws, size_t ws_bytes,
                          void *stream);
 
+/* y[i] = SnakeBeta(x[i]) = x + sin(x*exp(alpha))^2 / (exp(beta) + 1e-9)  (activations.py:107-120), through the
+ * device routines of the generator kernels (their sin^2 is a hand-written range reduction, not ocml's sinf). */
+int bvc_test_snakebeta(const float *d_x, int64_t n, float alpha, float beta, float *d_y, void *stream);
+
 /* ---- bench instrumentation: in-situ hipEvent timing of one kernel family inside the real schedule.
  * kind: 1 recurrent linear layer, 2 GRU cell, 3 vocoder conv, 4 batched phi_x GEMM, 5 STFT/mel,
  * 6 conv_post.  Every `sample_every`-th launch of that family is bracketed by an event pair on its

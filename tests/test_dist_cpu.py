@@ -88,3 +88,27 @@ def test_concurrent_stream_sets_without_gpu():
     import torch
     from bvcodec import dist as bdist
     assert bdist.concurrent_stream_sets(3, torch.device("cpu")) == [[]]
+
+
+def test_more_ranks_than_utterances_raises_everywhere():
+    """Every rank must refuse BEFORE any compute or collective (otherwise the empty rank fails alone and the others hang
+    in the gather).  Without a process group world = 1, so emulate the check through the public helper."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    from bvcodec import dist as bdist
+    x = torch.zeros(0, 16)
+    with pytest.raises(ValueError):
+        bdist.codec_sharded(_FakeCodec(), x, 3000)
+
+
+def test_default_checkpoint_paths_are_reported(tmp_path, monkeypatch):
+    """BVRNNCodecModel() with the reference's default arguments: the Git-LFS checkpoints are not shipped, so the
+    constructor must say which file it looked for and where to put it."""
+    import pytest
+    sys.path.insert(0, ROOT)
+    from bvcodec import model as bmodel
+    assert os.path.basename(bmodel.default_chkpt_bvrnn) == "bvrnn_var_bitrate_step200000"
+    assert os.path.basename(bmodel.default_chkpt_vocoder) == "bigvgan_causal_tiny_ftbvrnn_g_step3500000"
+    if not os.path.exists(bmodel.default_chkpt_bvrnn):
+        with pytest.raises(FileNotFoundError, match="BVC_CHKPT_DIR"):
+            bmodel.BVRNNCodecModel()

@@ -1,0 +1,54 @@
+"""The schedule bench.py reports as `multi_stream` - independent batches issued round-robin on several HIP
+streams through ONE model (shared weights, per-stream workspaces, one persistent recurrence at a time) - must
+give bit for bit what the same calls give one after the other on one stream."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _run(model, xs, L, streams, rounds):
+    outs = []
+    for k in range(rounds * len(xs)):
+        st = streams[k % len(streams)]
+        with torch.cuda.stream(st):
+            x = xs[k % len(xs)]
+            codes = model.encode(x, 3000)
+            outs.append((codes, model.decode(codes, L)))
+    for st in streams:
+        torch.cuda.current_stream(DEV).wait_stream(st)
+    torch.cuda.synchronize(DEV)
+    return outs
+
+
+@pytest.mark.parametrize("recurrence", ["persistent", "layers"])
+def test_four_stream_schedule_equals_serial(recurrence):
+    from gpu_common import make_model
+    from bvcodec import dist as bdist, synth
+    env = {"BVC_RECURRENCE": "layers"} if recurrence == "layers" else None
+    model, conf, _, _ = make_model(True, 1024, env=env)
+    B, L = 64, int(22050 * 1.2)
+    xs = [synth.synthetic_speech(B, L, seed=100 + i, kind="noise" if i % 2 else "speech").to(DEV) for i in range(4)]
+    serial = _run(model, xs, L, [torch.cuda.current_stream(DEV)], 1)
+    streams = bdist.concurrent_stream_sets(4, DEV)[0]           # what bench.py uses
+    assert len({s.cuda_stream for s in streams}) == 4
+    conc = _run(model, xs, L, streams, 3)
+    for k, (codes, wav) in enumerate(conc):
+        ref_codes, ref_wav = serial[k % 4]
+        assert torch.equal(codes, ref_codes), f"codes of call {k} differ under the {len(streams)}-stream schedule"
+        assert torch.equal(wav, ref_wav), f"waveform of call {k} differs under the {len(streams)}-stream schedule"
+    model.check_status()
+
+
+def test_many_workspaces_on_one_model():
+    """More streams (hence workspaces) than the launch-per-layer schedule's old 16-entry graph cache held."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    model, conf, _, _ = make_model(True, 1024, env={"BVC_RECURRENCE": "layers"})
+    B, L = 8, 22050 // 2
+    x = synth.synthetic_speech(B, L, seed=7, kind="speech").to(DEV)
+    ref = _run(model, [x], L, [torch.cuda.current_stream(DEV)], 1)[0]
+    streams = [torch.cuda.Stream(DEV) for _ in range(12)]
+    for codes, wav in _run(model, [x], L, streams, 24):
+        assert torch.equal(codes, ref[0]) and torch.equal(wav, ref[1])

@@ -1,0 +1,52 @@
+"""The RCCL leg of the multi-GPU path on the one GPU the box has: a 1-rank "nccl" process group (BVC_FORCE_PG=1),
+the per-step all_gather of bench.py on measured-concurrent streams, and the sharded facade.  Runs in a child
+process so that the communicator does not outlive the test."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import os, sys, tempfile, torch
+sys.path.insert(0, os.environ["BVC_ROOT"])
+from bvcodec import BVRNNCodecModel, config, dist as bdist, synth
+rank, world, device = bdist.init_from_env()
+assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" and world == 1
+conf = config.load_config(config.DEFAULT_CONFIG)
+d = tempfile.mkdtemp()
+p1, p2 = synth.write_checkpoints(conf, d, seed=1234)
+model = BVRNNCodecModel(config.DEFAULT_CONFIG, p1, p2).to(device)
+B, L = 16, 22050
+x = synth.synthetic_speech(B, L, seed=3, kind="speech").to(device)
+codes0 = model.encode(x, 3000); wav0 = model.decode(codes0, L)
+torch.cuda.synchronize()
+streams = bdist.concurrent_stream_sets(2, device)[0]
+outs = [torch.empty(world * B, L, device=device) for _ in streams]
+for k in range(4):                                  # two gathered steps per stream
+    with torch.cuda.stream(streams[k % 2]):
+        codes = model.encode(x, 3000)
+        wav = model.decode(codes, L)
+        torch.distributed.all_gather_into_tensor(outs[k % 2], wav)
+for st in streams:
+    torch.cuda.current_stream(device).wait_stream(st)
+torch.cuda.synchronize()
+for o in outs:
+    assert torch.equal(o, wav0), "gathered waveform differs from the local one"
+c2, w2 = bdist.codec_sharded(model, x, 3000, gather=True)
+assert torch.equal(c2, codes0) and torch.equal(w2, wav0)
+model.check_status()
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print("DIST-OK")
+'''
+
+
+def test_rccl_one_rank_gather_on_picked_streams():
+    env = dict(os.environ, BVC_FORCE_PG="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29600 + os.getpid() % 300), BVC_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0 and "DIST-OK" in r.stdout, r.stdout[-2000:] + "\n" + r.stderr[-4000:]

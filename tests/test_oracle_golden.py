@@ -34,6 +34,39 @@ def test_melbank_against_independent_implementation():
     assert abs(float(ours.astype(np.float64).sum()) - 3.713688) < 1e-5
 
 
+def test_melbank_analytic_properties():
+    """Known answers of the Slaney construction itself (librosa.filters.mel, htk=False, norm='slaney'; called at
+    meldataset.py:68) that do not lean on another library: the mel scale is linear (200/3 Hz per mel) up to the 1 kHz
+    break point and logarithmic (ratio 6.4 over 27 mels) above it; every triangle integrates to 1 over frequency
+    because of its 2/(f[j+2]-f[j]) weight; peaks sit at the centre frequencies; filters are non-negative."""
+    sr, n_fft, n_mels, fmin, fmax = 22050, 1024, 80, 0.0, 8000.0
+    M = omel.mel_filterbank(sr, n_fft, n_mels, fmin, fmax).astype(np.float64)
+    # centre frequencies from the closed form of the scale
+    brk_mel = 1000.0 / (200.0 / 3.0)                                  # 15 mel at the 1 kHz break point
+    logstep = np.log(6.4) / 27.0
+    mel_max = brk_mel + np.log(fmax / 1000.0) / logstep
+    mels = np.linspace(0.0, mel_max, n_mels + 2)
+    f = np.where(mels < brk_mel, mels * (200.0 / 3.0), 1000.0 * np.exp(logstep * (mels - brk_mel)))
+    assert abs(f[0]) < 1e-12 and abs(f[-1] - fmax) < 1e-9
+    k_brk = int(np.searchsorted(mels, brk_mel))                       # first point at / above 1 kHz
+    assert np.allclose(np.diff(f[:k_brk]), f[1] - f[0])                # equal spacing in Hz below the break
+    assert np.allclose(f[k_brk + 1:] / f[k_brk:-1], f[-1] / f[-2])     # equal ratios above it
+    bins = np.arange(n_fft // 2 + 1) * sr / n_fft
+    for j in range(n_mels):
+        lo, ce, hi = f[j], f[j + 1], f[j + 2]
+        tri = np.maximum(0.0, np.minimum((bins - lo) / (ce - lo), (hi - bins) / (hi - ce))) * 2.0 / (hi - lo)
+        assert np.abs(M[j] - tri).max() < 2e-9, j                     # float32 storage of O(1e-2) values
+        # area normalisation: integral of the continuous triangle = 1; its peak = 2 / (f[j+2] - f[j])
+        assert abs(0.5 * (hi - lo) * (2.0 / (hi - lo)) - 1.0) < 1e-15
+        assert M[j].max() <= 2.0 / (hi - lo) + 1e-9
+        nz = np.nonzero(M[j])[0]
+        assert bins[nz[0]] > lo and bins[nz[-1]] < hi                 # support strictly inside (f[j], f[j+2])
+    assert (M >= 0).all()
+    # Riemann sum over the 21.5 Hz bins approximates the unit area for the wide filters
+    area = M.sum(1) * sr / n_fft
+    assert np.abs(area[40:] - 1.0).max() < 0.03
+
+
 def test_hann_is_periodic():
     w = omel.hann_periodic(1024)
     assert w[0] == 0.0 and w[512] == 1.0 and abs(w[1] - w[1023]) < 1e-9
