@@ -26,7 +26,7 @@ def test_snakebeta_large_arguments(alpha, beta):
     arg = (x.numpy() * a32).astype(np.float32)                       # the reference multiplies in float32 first
     ref = x.numpy().astype(np.float64) + np.float64(ib32) * np.sin(arg.astype(np.float64)) ** 2
     got = y.cpu().numpy().astype(np.float64)
-    assert not np.isnan(got).any(), "scalar and packed SnakeBeta disagree somewhere"
+    assert not np.isnan(got).any()
     err = np.abs(got - ref)
     tol = 2.5e-7 * float(ib32) + 1.2e-7 * np.maximum(1.0, np.abs(ref))          # sin^2 error scaled by 1/(e^beta) + output rounding
     worst = int(np.argmax(err - tol))
