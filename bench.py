@@ -5,19 +5,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch: ``encode(x, 3000)`` then
-``decode(codes, L)`` on BASELINE.json configs[1] - 64 synthetic 5 s utterances at 22.05 kHz,
-config_varBitRate @ 3 kbit/s (35 bits/frame) - PER GPU (weak scaling: utterances are independent,
-each rank runs its own batch with no data-path collective; one RCCL all-gather of the decoded
-waveforms per step is the "final gather" of the north star).  Inputs are resident in HBM before the
-timed region.  Rank 0 prints ONE JSON line: metric/value (audio-seconds coded per wall-second,
-whole job), plus
+A "step" is one pass of the hot path over ONE batch: ``encode(x, 3000)`` then ``decode(codes, L)`` on
+BASELINE.json configs[1] - 64 synthetic 5 s utterances at 22.05 kHz, config_varBitRate @ 3 kbit/s (35
+bits/frame) - PER GPU (weak scaling: utterances are independent, each rank runs its own batch with no
+data-path collective; one RCCL all-gather of the decoded waveforms per step is the "final gather" of the
+north star).  Inputs are resident in HBM before the timed region; the K steps are issued back to back on
+one stream.  Rank 0 prints ONE JSON line: metric/value (audio-seconds coded per wall-second, whole job), plus
 
-  roofline     - the dominant kernel family, timed in situ with hipEvent pairs around sampled
-                 launches inside the real schedule (bvc_probe_*), algorithmic FLOPs per launch from
-                 SURVEY.md 8(d), against the fp32 MFMA peak of MI355X_MICROARCH.md
-  cpu_baseline - the CPU oracle (oracle/, PyTorch-CPU port of the reference op sequence) timed on
-                 the host cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline      - the dominant kernel (the persistent BVRNN recurrence, two launches per step) timed with HIP
+                  event pairs on its launch stream inside the real schedule (bvc_probe_*), algorithmic FLOPs per
+                  launch from SURVEY.md 8(d), against the fp32 MFMA peak of MI355X_MICROARCH.md;
+                  `rocprof_avg_us` / `frac_rocprof` quote the committed rocprofv3 --kernel-trace summary
+  parity        - after the timed region: the timed batch's codes against the CPU oracle on sampled
+                  utterances (differing bits, margin of the first divergence) and the decoded waveform's RMS error
+  multi_stream  - the same K steps issued round-robin on four HIP streams (4 x 64 utterances in flight)
+  cpu_baseline  - the CPU oracle (oracle/, PyTorch-CPU port of the reference op sequence) timed on the host
+                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+
+Other workloads of BASELINE.json: ``--seconds 10`` (the north-star target's utterance length, and with
+``--bitrate 1500|3000|6000`` one GPU's shard of configs[3]), ``--mode encode`` (configs[2]: front-end + coder only).
 """
 import argparse
 import ctypes
@@ -27,9 +33,9 @@ import sys
 import tempfile
 import time
 
-# The four-stream schedule relies on the runtime's default of 4 hardware queues per process (one per stream): 3, 5 or 6
-# queues cost 20-60 % of the throughput on this pool.  Pin the default unless the
-# caller chose otherwise; it must be in the environment before the HIP runtime initialises.
+# The multi-stream schedule relies on the runtime's default of 4 hardware queues per process (one per stream): 3, 5 or 6
+# queues cost 20-60 % of its throughput on this pool.  Pin the default unless the caller chose otherwise; it must be in the
+# environment before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 import torch
@@ -44,18 +50,24 @@ BATCH = 64
 SECONDS = 5.0
 BITRATE = 3000
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix = vector peak
-PROBE_NAMES = {1: "gemm_skinny_kernel<1,1,8,2,1> / <1,1,12,1,1> (recurrent BVRNN layer)", 2: "gemm_skinny_kernel<3,2,12,1,1,gate-interleaved> (GRU cell)",
-               3: "amp_pair_kernel / conv_mfma_kernel (BigVGAN convs)", 4: "gemm_batched_(lds_)kernel (phi_x / phi_z and the decoder's phi_z products over all frames)",
+PROBE_NAMES = {1: "bvrnn_flow_kernel<8,encode> / <8,decode> (persistent BVRNN recurrence: all frames of one call in one launch)",
+               3: "amp_pair_kernel / conv_mfma_kernel (BigVGAN convs)",
+               4: "gemm_batched_(lds_)kernel (phi_x / phi_z and the frame-independent halves of enc.0, dec.0 and the GRU input gates, all frames)",
                5: "stft_logmel_kernel", 6: "conv_post_kernel"}
+ROCPROF_SUMMARY = os.path.join(ROOT, "profiles", "r02_kernel_stats_default.csv")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_per_launch.csv")
 
 
-def flops_per_step(conf, B, T):
-    """Algorithmic FLOPs (2*MAC) of one encode+decode step, per kernel family."""
+def flops_per_step(conf, B, T, mode):
+    """Algorithmic FLOPs (2*MAC) of one step per kernel family -> {family: (flops, launches)}."""
     H, Z, X = conf["h_dim"], conf["z_dim"], conf["num_mels"]
-    enc_lin = 2 * H * H + H * H + H * Z + (Z * H + 2 * H * H) + (2 * H * H + 2 * H * H + H * X) + (X * H + 2 * H * H)
-    dec_lin = (Z * H + 2 * H * H) + (2 * H * H + 2 * H * H + H * X) + (X * H + 2 * H * H)
-    gru = 3 * H * (2 * H) + 3 * H * H
-    phix = X * H + 2 * H * H
+    # recurrence, per frame and utterance.  encode: enc.0 (h half), enc.2, enc.4, phi_z x3, dec.0 (both halves), dec.2/4/6,
+    # phi_x x3, GRU (W_ih 3Hx2H, W_hh 3HxH).  decode: dec.0 (h half), dec.2/4/6, phi_x x3, GRU (W_ih[:, :H], W_hh)
+    rec_enc = (H * H + H * H + H * Z) + (Z * H + 2 * H * H) + (2 * H * H + 2 * H * H + H * X) + (X * H + 2 * H * H) + 9 * H * H
+    rec_dec = (H * H + 2 * H * H + H * X) + (X * H + 2 * H * H) + 6 * H * H
+    # batched over all frames.  encode: phi_x + enc.0[:, :H]; decode: phi_z + dec.0[:, :H] + W_ih[:, H:]
+    bat_enc = (X * H + 2 * H * H) + H * H
+    bat_dec = (Z * H + 2 * H * H) + H * H + 3 * H * H
     v = conf["vocoder_config"]
     ch, rate, voc = v["upsample_initial_channel"], 1, conf["num_mels"] * v["upsample_initial_channel"] * 7
     for u, k in zip(v["upsample_rates"], v["upsample_kernel_sizes"]):
@@ -65,63 +77,106 @@ def flops_per_step(conf, B, T):
         voc += rate * ch * ch * sum(v["resblock_kernel_sizes"]) * 6  # 3 AMP blocks x 3 x 2 convs
     post = rate * ch * 7
     BT = B * T
+    full = mode == "codec"
     return {
-        1: (2.0 * BT * (enc_lin + dec_lin), T * (13 + 10)),
-        2: (2.0 * BT * 2 * gru, 2 * T),
-        3: (2.0 * BT * voc, 1 + len(v["upsample_rates"]) * (1 + 9)),      # conv_pre + per stage: ConvT + 9 fused AMP iterations
-        4: (2.0 * BT * phix, 3),
+        1: (2.0 * BT * (rec_enc + (rec_dec if full else 0)), 2 if full else 1),
+        3: (2.0 * BT * voc if full else 0.0, 1 + len(v["upsample_rates"]) * (1 + 9)),   # conv_pre + per stage: ConvT + 9 fused AMP iterations
+        4: (2.0 * BT * (bat_enc + (bat_dec if full else 0)), 9 if full else 4),
         5: (2.0 * BT * 5 * 512 * 9 * 1.0, 1),
-        6: (2.0 * BT * post, 1),
+        6: (2.0 * BT * post if full else 0.0, 1),
     }
 
 
-def pmc_traffic_bytes(kernel_prefix):
-    """HBM-side bytes per launch of a kernel family from the committed rocprofv3 --pmc pass
-    (FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE), launch-weighted.
-    PMC collection serialises every dispatch, so it is a separate pass (tools/pmc_probe.py), not part
-    of this run; None if the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic_per_launch.csv")
-    if not os.path.exists(path):
+def rocprof_avg_us(kernel_substr):
+    """Launch-weighted average duration of a kernel family in the committed rocprofv3 --kernel-trace --stats summary of
+    the default command (profiles/, regenerated by tools/profile_round.sh); None if absent."""
+    if not os.path.exists(ROCPROF_SUMMARY):
         return None
     import csv
     tot, n = 0.0, 0
-    for r in csv.DictReader(open(path)):
-        if kernel_prefix in r["kernel"]:
+    for r in csv.DictReader(open(ROCPROF_SUMMARY)):
+        if kernel_substr in r.get("Name", ""):
+            tot += float(r["TotalDurationNs"]) / 1e3
+            n += int(r["Calls"])
+    return round(tot / n, 3) if n else None
+
+
+def pmc_traffic_bytes(kernel_substr):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc pass (FETCH_SIZE x2 per the gfx950 correction of
+    MI355X_MICROARCH.md + WRITE_SIZE), launch-weighted.  PMC collection serialises every dispatch, so it is a separate pass
+    (tools/pmc_probe.py), not part of this run; None if the summary is absent."""
+    if not os.path.exists(PMC_SUMMARY):
+        return None
+    import csv
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(PMC_SUMMARY)):
+        if kernel_substr in r["kernel"]:
             k = int(r["launches"])
             tot += k * (2.0 * float(r["FETCH_SIZE_KB_raw_avg"]) + float(r["WRITE_SIZE_KB_avg"])) * 1024.0
             n += k
     return round(tot / n) if n else None
 
 
-def cpu_baseline(conf):
-    """Oracle (PyTorch-CPU port of the reference op sequence) on a bounded sample: 32 x 5 s, half the GPU
-    batch (about 10 s of CPU work on the box's 16 cores)."""
+def oracle_leg(conf, model, x, codes, wav, L, bitrate, mode, with_baseline):
+    """The CPU oracle as checker and as reference point (rank 0).  parity: the oracle encodes sampled utterances of the TIMED
+    batch; the codes the GPU produced in the timed region are compared bit by bit; the oracle then decodes the GPU's codes
+    and the waveform is compared.  cpu_baseline: the oracle timed on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import codec as ocodec
+    from parity_stats import divergence_stats
     threads = min(16, os.cpu_count() or 1)      # the 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(threads)
     oc = ocodec.OracleCodec(conf, synth.bvrnn_state_dict(conf, 1234), synth.generator_state_dict(conf, 1235))
-    b = 32
-    x = synth.synthetic_speech(b, int(FS * SECONDS), seed=0, kind="noise")
-    oc.forward(x[:1, :FS], BITRATE)                                  # warm-up (thread pools, mkldnn)
-    t0 = time.time()
-    oc.forward(x, BITRATE)
-    dt = time.time() - t0
-    return {"value": round(b * SECONDS / dt, 3), "unit": "audio-seconds/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{b} x {SECONDS:g} s utterances, encode+decode @ {BITRATE} bit/s, "
-                                      f"oracle (PyTorch-CPU eager fp32), {dt:.1f} s wall"}
+    out = {}
+    idx = [0, x.shape[0] // 3, (2 * x.shape[0]) // 3, x.shape[0] - 1]
+    xs = x[idx].cpu()
+    r = oc.encode(xs, bitrate, full=True)
+    nb = int(model.bits_per_frame(bitrate)) if conf["var_bit"] else conf["z_dim"]
+    st = divergence_stats(codes[idx].cpu(), r["codes"], r["prob"], min(nb, conf["z_dim"]))
+    par = {"checker": "oracle/ (CPU restatement of the reference, pinned to its goldens)", "utterances_checked": idx,
+           "code_bits_checked": len(idx) * codes.shape[1] * min(nb, conf["z_dim"]),
+           "code_bits_differing": st["mismatching_bits_total"], "utterances_diverged": st["diverged_utterances"],
+           "max_first_divergence_margin": st["max_first_divergence_margin"],
+           "bits_within_1e-6_of_a_tie": st["bits_within_1e-6_of_a_tie"]}
+    if mode == "codec":
+        ref_wav = oc.decode(codes[idx[:2]].cpu(), L)
+        par["waveform_rms_error"] = float((wav[idx[:2]].cpu() - ref_wav).pow(2).mean().sqrt())
+        par["waveform_rms"] = float(ref_wav.pow(2).mean().sqrt())
+        par["waveform_utterances_checked"] = idx[:2]
+    out["parity"] = par
+    if with_baseline:
+        b = 32
+        secs = L / FS
+        xb = synth.synthetic_speech(b, L if secs <= 5 else int(FS * 5), seed=0, kind="noise")
+        fn = (lambda t: oc.forward(t, bitrate)) if mode == "codec" else (lambda t: oc.encode(t, bitrate))
+        fn(xb[:1, :FS])                                                  # warm-up (thread pools, mkldnn)
+        t0 = time.time()
+        fn(xb)
+        dt = time.time() - t0
+        out["cpu_baseline"] = {"value": round(b * xb.shape[1] / FS / dt, 3), "unit": "audio-seconds/s", "cores": torch.get_num_threads(),
+                               "kind": "port", "sample": f"{b} x {xb.shape[1] / FS:g} s utterances, "
+                                                         f"{'encode+decode' if mode == 'codec' else 'encode only'} @ {bitrate} bit/s, "
+                                                         f"oracle (PyTorch-CPU eager fp32), {dt:.1f} s wall"}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=SECONDS)
-    ap.add_argument("--streams", type=int, default=4,
-                    help="HIP streams the K steps are issued on round-robin (independent batches overlap)")
+    ap.add_argument("--bitrate", type=float, default=BITRATE)
+    ap.add_argument("--mode", choices=["codec", "encode"], default="codec",
+                    help="codec: encode -> BigVGAN decode (configs[1]); encode: STFT/mel + BVRNN.encode only (configs[2])")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams of the HEADLINE measurement (1: one batch at a time; the 4-stream figure is reported "
+                         "beside it as multi_stream)")
+    ap.add_argument("--multi-streams", type=int, default=4, help="streams of the multi_stream figure (0: skip)")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
 
@@ -149,15 +204,16 @@ def main():
 
     L = int(FS * a.seconds)
     B = a.batch
+    full = a.mode == "codec"
     x = synth.synthetic_speech(B, L, seed=rank, kind="noise").to(device)      # resident before timing
     use_pg = torch.distributed.is_available() and torch.distributed.is_initialized()
-    nstreams = max(1, a.streams)
-    gathered = ([torch.empty(world * B, L, device=device) for _ in range(nstreams)]
-                if (use_pg and not a.no_gather) else None)
+    nslots = max(1, a.streams, a.multi_streams)
+    gathered = ([torch.empty(world * B, L, device=device) for _ in range(nslots)]
+                if (use_pg and full and not a.no_gather) else None)
 
     def local_step():
-        codes = model.encode(x, BITRATE)
-        return codes, model.decode(codes, L)
+        codes = model.encode(x, a.bitrate)
+        return codes, (model.decode(codes, L) if full else None)
 
     def step(slot=0):
         codes, wav = local_step()
@@ -165,124 +221,106 @@ def main():
             torch.distributed.all_gather_into_tensor(gathered[slot], wav)
         return codes, wav
 
-    # Steps are independent batches: issue them round-robin on `--streams` HIP streams so that the
-    # latency-bound recurrent chain of one batch overlaps the next batch's work (every step still
-    # runs the full encode -> decode; all K steps complete inside the timed bracket).
-    # ... on streams that really are concurrent: which HIP streams share a hardware queue is not visible through the API
-    # and shifts when an RCCL communicator exists, so the set is measured (bvcodec.dist.concurrent_streams, ~0.3 s)
-    try:
-        stream_sets = bdist.concurrent_stream_sets(nstreams, device) if nstreams > 1 else [[torch.cuda.Stream(device)]]
-    except Exception as e:                      # never let the placement probe take the benchmark down
-        print(f"warning: stream placement probe failed ({e!r}); using the first {nstreams} streams", file=sys.stderr)
-        stream_sets = [[torch.cuda.Stream(device) for _ in range(nstreams)]]
-    streams = stream_sets[0]
-
-    def run(n):
+    def run(n, streams, fn=step):
+        """n steps round-robin on `streams` (one stream: back to back); every step completes before run() returns"""
         last = None
         for k in range(n):
-            st = streams[k % len(streams)]
-            with torch.cuda.stream(st):
-                last = step(k % len(streams))
+            with torch.cuda.stream(streams[k % len(streams)]):
+                last = fn(k % len(streams))
         for st in streams:
             torch.cuda.current_stream(device).wait_stream(st)
         return last
 
-    if len(stream_sets) > 1:
-        # the pair test uses tiny kernels; settle between the candidate sets with the real workload (untimed, before warm-up)
-        # (local steps only: the number of candidate sets may differ between ranks, so no collective in here)
-        def run_local(cand, n):
-            for k in range(n):
-                with torch.cuda.stream(cand[k % len(cand)]):
-                    local_step()
-            torch.cuda.synchronize(device)
-
+    def pick_streams(n):
+        # streams that really are concurrent: which HIP streams share a hardware queue is not visible through the API and
+        # shifts when an RCCL communicator exists, so the set is measured (bvcodec.dist.concurrent_stream_sets, ~0.3 s) and
+        # the candidate sets are settled with the real workload (local steps only: no collective in the probe)
+        if n <= 1:
+            return [torch.cuda.current_stream(device)]
+        try:
+            sets = bdist.concurrent_stream_sets(n, device)
+        except Exception as e:                      # never let the placement probe take the benchmark down
+            print(f"warning: stream placement probe failed ({e!r}); using the first {n} streams", file=sys.stderr)
+            return [torch.cuda.Stream(device) for _ in range(n)]
         best = None
-        for cand in stream_sets:
-            run_local(cand, len(cand))
+        for cand in sets:
+            run(len(cand), cand, lambda _s: local_step())
+            torch.cuda.synchronize(device)
             t_try = time.perf_counter()
-            run_local(cand, 2 * len(cand))
+            run(2 * len(cand), cand, lambda _s: local_step())
+            torch.cuda.synchronize(device)
             t_try = time.perf_counter() - t_try
             if best is None or t_try < best[0]:
                 best = (t_try, cand)
-        streams = best[1]
-    run(max(a.warmup, len(streams)) if a.warmup else 0)
+        return best[1]
+
+    def timed(n, streams, fn=step):
+        if use_pg:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        last = run(n, streams, fn)
+        torch.cuda.synchronize(device)
+        if use_pg:
+            torch.distributed.barrier()
+        return time.perf_counter() - t0, last
+
+    streams = pick_streams(a.streams)
+    if a.warmup:
+        run(max(a.warmup, len(streams)), streams)
+    elapsed_local, (codes, wav) = timed(a.steps, streams)
+    elapsed, rank_ms = elapsed_local, [round(1e3 * elapsed_local / a.steps, 3)]
     if use_pg:
-        torch.distributed.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    codes, wav = run(a.steps)
-    torch.cuda.synchronize(device)
-    if use_pg:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_pg:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert torch.isfinite(wav).all() and codes.shape[2] == conf["z_dim"]
+        tl = torch.tensor([elapsed_local], device=device, dtype=torch.float64)
+        tall = [torch.zeros_like(tl) for _ in range(world)]
+        torch.distributed.all_gather(tall, tl)
+        rank_ms = [round(1e3 * float(t.item()) / a.steps, 3) for t in tall]
+        elapsed = max(float(t.item()) for t in tall)             # the job is as slow as its slowest rank
+    assert codes.shape[2] == conf["z_dim"] and (wav is None or torch.isfinite(wav).all())
+    model.check_status()                                          # no recurrence kernel may have given up waiting
 
     T = codes.shape[1]
+    names = {"codec": "full encode -> BigVGAN decode", "encode": "encode only (STFT/mel + BVRNN.encode, no vocoder)"}
+    cfgname = ("configs[1]" if (full and a.seconds == 5.0) else "configs[2]" if a.seconds == 5.0 else
+               "configs[3] shard (one GPU's 64 of 512 x 10 s)" if (full and a.seconds == 10.0) else "custom")
     out = {
-        "metric": "audio-seconds coded per wall-second (encode+decode), 22.05 kHz @ 3 kbit/s",
+        "metric": "audio-seconds coded per wall-second (encode+decode), 22.05 kHz @ 3 kbit/s" if (full and a.bitrate == BITRATE) else
+                  f"audio-seconds coded per wall-second ({'encode+decode' if full else 'encode only'}), 22.05 kHz @ {a.bitrate:g} bit/s",
         "value": round(world * B * a.seconds * a.steps / elapsed, 2),
         "unit": "audio-seconds/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(1e3 * elapsed / a.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: batch {B} x {a.seconds:g} s utterances per GPU, "
-                               f"config_varBitRate @ {BITRATE} bit/s (35 bits/frame), full encode -> BigVGAN decode",
+        "config": {"workload": f"BASELINE {cfgname}: batch {B} x {a.seconds:g} s utterances per GPU, config_varBitRate @ "
+                               f"{a.bitrate:g} bit/s ({int(model.bits_per_frame(a.bitrate))} bits/frame), {names[a.mode]}; "
+                               f"{'one batch at a time on one stream' if len(streams) == 1 else str(len(streams)) + ' batches in flight on ' + str(len(streams)) + ' streams'}",
                    "frames_per_utterance": T, "weights": "seeded synthetic (checkpoints are LFS pointers)",
                    "gather": "rccl all_gather of decoded waveforms" if gathered is not None else "none",
                    "streams": len(streams)},
+        "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
     }
 
-    if rank == 0 and len(streams) > 1:
-        # for reference: the same K steps issued back to back on ONE stream (latency-oriented number)
-        torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        for _ in range(a.steps):
-            local_step()
-        torch.cuda.synchronize(device)
-        dt1 = time.perf_counter() - t1
-        out["single_stream"] = {"value": round(B * a.seconds * a.steps / dt1, 2), "ms_per_step": round(1e3 * dt1 / a.steps, 3),
-                                "note": "one rank, one stream, no gather"}
+    if a.multi_streams > 1 and len(streams) == 1:
+        # the same K steps with several independent batches in flight (throughput-oriented; results are bit-identical to the
+        # serial schedule: tests/test_gpu_concurrency.py).  Timed like the headline (barrier + synchronize, max over ranks).
+        ms = pick_streams(a.multi_streams)
+        run(len(ms), ms)
+        dtm, _ = timed(a.steps, ms)
+        if use_pg:
+            tm = torch.tensor([dtm], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+            dtm = float(tm.item())
+        out["multi_stream"] = {"value": round(world * B * a.seconds * a.steps / dtm, 2), "ms_per_step": round(1e3 * dtm / a.steps, 3),
+                               "streams": len(ms), "note": f"{len(ms)} x {B} utterances in flight per GPU, same steps round-robin on "
+                                                           f"{len(ms)} HIP streams"}
+        model.check_status()
 
     if rank == 0 and not a.no_roofline:
         lib = _abi.load()
-        fam = flops_per_step(conf, B, T)
+        fam = flops_per_step(conf, B, T, a.mode)
         rows = {}
-
-        def kread(lo, hi):
-            mean, mn, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
-            _abi.check(lib.bvc_kprobe_read(lo, hi, ctypes.byref(mean), ctypes.byref(mn), ctypes.byref(n)))
-            return mean.value, n.value
-
-        # recurrent kernels are replayed from a hipGraph: in-kernel wall-clock stamps (bvc_kprobe_*)
-        _abi.check(lib.bvc_kprobe_enable(1))
-        c_ = model.encode(x, BITRATE)
-        e_lin, e_nl = kread(0, 13)
-        e_gru, e_ng = kread(13, 14)
-        model.decode(c_, L)
-        d_lin, d_nl = kread(0, 7)
-        d_gru, d_ng = kread(7, 8)
-        _abi.check(lib.bvc_kprobe_enable(0))
-        fam[1] = (fam[1][0] - 2.0 * B * T * (conf["z_dim"] * conf["h_dim"] + 2 * conf["h_dim"] ** 2), T * (13 + 7))
-        fam[4] = (fam[4][0] + 2.0 * B * T * (conf["z_dim"] * conf["h_dim"] + 2 * conf["h_dim"] ** 2), 6)
-        if os.environ.get("BVC_NO_PRECOMP", "0") != "1" and os.environ.get("BVC_SIDE_BRANCH", "0") != "1":
-            # decode: the phi_z halves of dec.0 (H x H) and of the GRU input product (3H x H) are batched over all frames
-            hh = 2.0 * B * T * conf["h_dim"] ** 2
-            fam[1] = (fam[1][0] - hh, fam[1][1])
-            fam[2] = (fam[2][0] - 3 * hh, fam[2][1])
-            fam[4] = (fam[4][0] + 4 * hh, 8)
-        for kind, mean, n in ((1, (e_lin * e_nl + d_lin * d_nl) / max(1, e_nl + d_nl), e_nl + d_nl),
-                              (2, (e_gru * e_ng + d_gru * d_ng) / max(1, e_ng + d_ng), e_ng + d_ng)):
-            fl, launches = fam[kind]
-            rows[kind] = {"kernel": PROBE_NAMES[kind], "launches_per_step": launches, "sampled": n,
-                          "mean_us": round(mean, 3), "total_ms": round(mean * launches / 1e3, 3),
-                          "tflops": round(fl / launches / (mean * 1e-6) / 1e12, 3) if mean else 0.0,
-                          "timer": "in-kernel wall_clock64 (first workgroup start -> last workgroup end)"}
-        for kind in (3, 4, 5, 6):               # eagerly launched kernels: hipEvent pairs around every launch
+        for kind in ((1, 3, 4, 5, 6) if full else (1, 4, 5)):               # HIP event pairs around every launch of the family
             _abi.check(lib.bvc_probe_begin(kind, 1, 4096))
             local_step()                        # rank 0 only: no collective here
             mean, mn, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
@@ -294,31 +332,37 @@ def main():
                           "timer": "hipEvent pair on the launch stream"}
         dom = max(rows, key=lambda k: rows[k]["total_ms"])
         r = rows[dom]
+        rp = rocprof_avg_us("bvrnn_flow_kernel") if dom == 1 else None
+        fl, launches = fam[dom]
         out["roofline"] = {"bound": "mfma", "achieved": r["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(r["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                           "traffic": pmc_traffic_bytes("gemm_skinny_kernel<1, 1,") if dom == 1 else None,
-                           "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass; "
-                                           "algorithmic: 4.5e6 for a 1024x1024 layer at B=64)",
+                           "traffic": pmc_traffic_bytes("bvrnn_flow_kernel") if dom == 1 else None,
+                           "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass: "
+                                           "profiles/r02_pmc_per_launch.csv); algorithmic: the weights once per frame "
+                                           "(85 / 60 MB encode / decode, served by the 256 MB Infinity Cache) + 0.25 MB per audio-second of I/O",
                            "kernel": r["kernel"], "mean_launch_us": r["mean_us"],
-                           "launches_per_step": r["launches_per_step"],
+                           "launches_per_step": r["launches_per_step"], "gflop_per_launch": round(fl / launches / 1e9, 1),
                            "timer": r["timer"],
-                           "rocprof_avg_us": "5.2 (rocprofv3 --kernel-trace, dispatch-inclusive, --streams 1: profiles/r01_p_kernel_stats_final_1stream.csv)",
-                           "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32); algorithmic FLOPs per launch / "
-                                   "launch duration measured in situ inside the real schedule.  The layer is not MFMA-limited: "
-                                   "each 16x16 output tile pulls 128 KB of operands through its CU's L1, and chains of this "
-                                   "layer shape saturate the chip at 0.37 layers/us = 50 TFLOP/s whatever the tiling "
-                                   "(profiles/r01_concurrency_microbench.txt)"}
+                           "rocprof_avg_us": rp,
+                           "frac_rocprof": round(fl / launches / (rp * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if rp else None,
+                           "rocprof_source": "profiles/r02_kernel_stats_default.csv (rocprofv3 --kernel-trace --stats of this command)",
+                           "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32).  One launch runs every layer of every frame; it is "
+                                   "bound by the hand-offs between dependent layers (two write-through / L1-bypassing round trips "
+                                   "of ~0.85 us per layer) and by the per-CU operand stream, not by the matrix pipe (DESIGN.md 4)"}
         # SURVEY.md 8(d) also asks for the whole path against the fp32 peak: algorithmic FLOPs of a step (all families)
-        # over the measured step time of the timed region (the kernels of the streams overlap, so this is not the
-        # sum of the per-launch figures above)
-        step_flops = sum(f for f, _ in flops_per_step(conf, B, T).values())
+        # over the measured step time of the timed region
+        step_flops = sum(f for f, _ in fam.values())
         whole = step_flops / (elapsed / a.steps) / 1e12
         out["roofline"]["whole_path"] = {"achieved": round(whole, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                          "frac": round(whole / PEAK_FP32_MFMA_TFLOPS, 4),
                                          "gflop_per_audio_second": round(step_flops / (B * a.seconds) / 1e9, 3)}
         out["kernel_families"] = rows
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(conf)
+    if rank == 0 and not (a.no_parity and (a.no_cpu_baseline or world > 1)):
+        leg = oracle_leg(conf, model, x, codes, wav, L, a.bitrate, a.mode, with_baseline=(world == 1 and not a.no_cpu_baseline))
+        if not a.no_parity:
+            out["parity"] = leg["parity"]
+        if "cpu_baseline" in leg:
+            out["cpu_baseline"] = leg["cpu_baseline"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_pg:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Small eager (no hipGraph) workload for rocprofv3 --pmc passes: B=64, a few frames of
-encode + decode, so that every kernel family appears with its C2 per-launch shape."""
+"""Workload for the rocprofv3 --pmc passes: B=64, `frames` frames (argv[1], default 12; 430 = configs[1]) of
+encode + decode twice, so that every kernel family appears with its configs[1] per-launch shape.  (BVC_NO_GRAPH only
+matters for the launch-per-layer schedule, BVC_RECURRENCE=layers.)"""
 import os
 import sys
 
