@@ -32,6 +32,8 @@ def build(force=False, verbose=True):
         if force or _stale(o, [s] + hdrs):
             extra = (["-mllvm", "-amdgpu-kernarg-preload-count=16"]
                      if (src == "k_gemm.hip" and os.environ.get("BVC_KERNARG_PRELOAD", "0") == "1") else [])
+            if src == "k_flow.hip" and os.environ.get("BVC_FLOW_WAVES"):       # experiments: register budget of the persistent kernel
+                extra = extra + ["-DBVC_FLOW_WAVES_PER_SIMD=" + os.environ["BVC_FLOW_WAVES"]]
             cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -875,8 +875,9 @@ inline float *flow_buf(const Workspace &w, int id, int parity) { return w.flow +
 // The persistent kernel needs all its workgroups resident at once (they wait for each other), so launches from
 // different streams are serialised through one event: at most one is in flight per process and device.
 std::mutex g_flow_mu;
-hipEvent_t g_flow_ev[16] = {};
-bool g_flow_ev_used[16] = {};
+constexpr int FLOW_MAX_TICKETS = 2;
+hipEvent_t g_flow_ev[16][FLOW_MAX_TICKETS] = {};
+unsigned long long g_flow_n[16] = {};
 
 // All T frames of BVRNN.encode (encode = true) or BVRNN.decode in one launch.  w.part_dec0 (and w.part_gru for decode)
 // must hold the pre-computed halves; h0 may be null (zero state).
@@ -918,12 +919,14 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, const float *d
         int dev = 0;
         BVC_HIP_TRY(hipGetDevice(&dev));
         dev &= 15;
-        if (!g_flow_ev[dev]) BVC_HIP_TRY(hipEventCreateWithFlags(&g_flow_ev[dev], hipEventDisableTiming));
-        if (g_flow_ev_used[dev]) BVC_HIP_TRY(hipStreamWaitEvent(s, g_flow_ev[dev], 0));
+        static const int tickets = (getenv("BVC_FLOW_TICKETS") && atoi(getenv("BVC_FLOW_TICKETS")) == 2) ? 2 : 1;
+        hipEvent_t &ev = g_flow_ev[dev][g_flow_n[dev] % tickets];        // the launch `tickets` launches ago must have finished
+        if (!ev) BVC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        if (g_flow_n[dev] >= (unsigned long long)tickets) BVC_HIP_TRY(hipStreamWaitEvent(s, ev, 0));
         ProbeScope probe(PK_LINEAR, s);
         if ((rc = launch_flow(a, w.flow_args, m->flow_perh, encode, s))) return rc;
-        BVC_HIP_TRY(hipEventRecord(g_flow_ev[dev], s));
-        g_flow_ev_used[dev] = true;
+        BVC_HIP_TRY(hipEventRecord(ev, s));
+        ++g_flow_n[dev];
     }
     if (d_hT && (rc = launch_repack_rows(flow_buf(w, FB_H, (int)(T & 1)), d_hT, H, B, H, 1, s))) return rc;
     return BVC_OK;

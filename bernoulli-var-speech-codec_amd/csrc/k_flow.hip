@@ -423,8 +423,11 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
 
 // PERH: k-blocks per wave of an h_dim-sized operand (h_dim = 128 * PERH, or h_dim <= 128 for PERH = 1: then a wave owns at
 // most one k-block); the z_dim- and num_mels-sized operands (<= 128) always have one k-block per wave.
+#ifndef BVC_FLOW_WAVES_PER_SIMD
+#define BVC_FLOW_WAVES_PER_SIMD 2
+#endif
 template <int PERH, bool ENCODE>
-__global__ __launch_bounds__(512) void bvrnn_flow_kernel(const FlowArgs *a0) {
+__global__ __launch_bounds__(512, BVC_FLOW_WAVES_PER_SIMD) void bvrnn_flow_kernel(const FlowArgs *a0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][8][256] layer partials | [8][6][256] GRU partials
     const int tid = threadIdx.x;
     FlowCtx c;
