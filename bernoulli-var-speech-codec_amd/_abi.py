@@ -54,6 +54,10 @@ SIGNATURES = {
     "bvc_vocoder_stream_destroy": (None, [_vp]),
     "bvc_vocoder_stream_reset": (ctypes.c_int, [_vp, _vp]),
     "bvc_vocoder_stream_push": (ctypes.c_int, [_vp, _vp, _i32, _f, _vp, _vp]),
+    "bvc_stream_codec_create": (ctypes.c_int, [_vp, _i32, _i32, _f, _f, _f, ctypes.POINTER(_vp)]),
+    "bvc_stream_codec_destroy": (None, [_vp]),
+    "bvc_stream_codec_buffers": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i32)]),
+    "bvc_stream_codec_tick": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), _vp]),
     "bvc_encode": (ctypes.c_int, [_vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _sz, _vp]),
     "bvc_decode": (ctypes.c_int, [_vp, _vp, _i32, _i64, _i64, _f, _vp, _vp, _sz, _vp]),
     "bvc_resample_poly": (ctypes.c_int, [_vp, _i32, _i64, _vp, _i32, _i32, _i32, _i64, _vp, _i64, _vp]),

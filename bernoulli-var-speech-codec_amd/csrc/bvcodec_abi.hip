@@ -31,6 +31,7 @@ struct ProbeState {
 };
 static ProbeState g_probe;
 static bool g_capturing = false;           // no event probes while a stream is being captured
+static thread_local bool g_stream_tick = false;   // inside bvc_stream_codec_tick: launch-per-layer schedule, launched eagerly (the tick itself is the graph)
 
 // in-kernel timestamp probes for the graph-replayed recurrent kernels (wall_clock64, 100 MHz)
 struct KProbe {
@@ -528,6 +529,7 @@ enum { OP_KERNEL = 0, OP_RECORD = 1, OP_WAIT = 2 };
 enum { BR_MAIN = 0, BR_SIDE = 1 };
 struct StepNode { int op; int branch; int event; GemmParams p; int epi; };
 enum { STEP_ENCODE = 0, STEP_DECODE = 1, STEP_DECODE_PRE = 2 };   // _PRE: phi_z halves of dec.0 / GRU arrive pre-computed
+constexpr int64_t SMALL_T_FRAMES = 4;          // up to this many frames per call the all-frame MLPs run frame by frame on the recurrent-layer kernel
 constexpr int64_t PRECOMP_MIN_FRAMES = 16;     // below this (streaming hops) the two extra batched GEMMs cost more than they save
 enum { EV_START = 0, EV_DEC0H = 1, EV_PZ = 2, EV_GATES = 3, EV_COUNT = 4 };
 
@@ -770,7 +772,7 @@ int run_recurrence(const bvc_model *m, const Workspace &w, void *ws_base, int B,
     const std::vector<StepNode> plan = build_step(m, w, B, kind);
     // (begin_call was given count_kernels(build_step(...)) kernels per step)
     int rc;
-    if (!m->use_graph) {
+    if (!m->use_graph || g_stream_tick) {
         int rc2;
         for (int64_t t = 0; t < T; ++t)
             if ((rc2 = launch_steps(m, plan, w, 1, s, nullptr))) return rc2;
@@ -868,7 +870,7 @@ void flow_layers(const bvc_model *m, bool encode, FlowArgs *a) {
     a->hb = hb; a->zb = m->cfg.z_dim / 16; a->xb = m->cfg.num_mels / 16;
 }
 
-inline bool flow_usable(const bvc_model *m, int B) { return m->use_flow && m->flow_perh > 0 && (B + 15) / 16 <= 4; }
+inline bool flow_usable(const bvc_model *m, int B) { return m->use_flow && !g_stream_tick && m->flow_perh > 0 && (B + 15) / 16 <= 4; }
 
 inline float *flow_buf(const Workspace &w, int id, int parity) { return w.flow + (size_t)(id * 2 + parity) * w.flow_slot; }
 
@@ -942,6 +944,17 @@ int batched_mlp3(const bvc_model *m, const Workspace &w, const Linear (&l)[3], c
     const int mt16 = ((B + 15) / 16) * 16;
     const int BT = (int)((long long)B * T);
     int rc;
+    if (T <= SMALL_T_FRAMES) {
+        // a streaming hop (1-2 frames): B*T rows fill a handful of the batched kernel's 128x128 tiles (102 us per 1024^2
+        // layer at 256 streams); the recurrent-layer kernel takes the rows of ONE frame (row stride T*K0) in 10 us and
+        // writes the fragment-packed frame matrix directly
+        for (int64_t t = 0; t < T; ++t) {
+            if ((rc = launch_gemm_skinny(lin_params(l[0], dp_static(in + t * K0, T * K0), B, dp_static(w.pxC, H, 1)), EPI_ELU, s, m->mtw))) return rc;
+            if ((rc = launch_gemm_skinny(lin_params(l[1], dp_static(w.pxC, H, 1), B, dp_static(w.pxB, H, 1)), EPI_ELU, s, m->mtw))) return rc;
+            if ((rc = launch_gemm_skinny(lin_params(l[2], dp_static(w.pxB, H, 1), B, dp_static(w.pxA + t * (int64_t)mt16 * H, H, 1)), EPI_ELU, s, m->mtw))) return rc;
+        }
+        return BVC_OK;
+    }
     if ((rc = launch_gemm_batched(in, K0, l[0].w, K0, l[0].b, BT, H, K0, 1, w.pxC, H, s))) return rc;
     if ((rc = launch_gemm_batched(w.pxC, H, l[1].w, H, l[1].b, BT, H, H, 1, w.pxB, H, s))) return rc;
     return launch_gemm_batched(w.pxB, H, l[2].w, H, l[2].b, BT, H, H, 1, w.pxA, H, s, GO_PACKED_FROM_UTT, T, mt16);
@@ -1220,6 +1233,7 @@ struct bvc_vocoder_stream {
 
 namespace {
 
+const int64_t STREAM_WARM_FRAMES = 32;   // rate * 32 - 64 >= 60 = the longest receptive field of an AMP pair, for every stage rate >= 8
 const int STREAM_H = 64;     // history rows per stage: >= (ks-1)*dil + (ks-1) of every AMP pair (max 60) and a multiple of every rate
 
 int stream_push(bvc_vocoder_stream *st, const float *d_mel, int k, float div, float *d_wav, hipStream_t s) {
@@ -1253,7 +1267,10 @@ int stream_push(bvc_vocoder_stream *st, const float *d_mel, int k, float div, fl
             if ((rc = launch_conv_mfma(m->ups[i], in, hq + nq, X.buf[p], hq + nq, B, CE_STORE, nullptr, nullptr, 1.0f, s, &w))) return rc;
         }
         const long long L = X.H + (long long)X.rate * k;
-        ConvWindow w{bs(X), bs(X), X.H, (long long)X.rate * st->frames - X.H};
+        // t_origin only decides which rows lie before the start of the signal; from STREAM_WARM_FRAMES frames on none
+        // does, so the value is frozen there (a hop captured into a hipGraph then replays with identical arguments)
+        const long long fr = st->frames < STREAM_WARM_FRAMES ? st->frames : STREAM_WARM_FRAMES;
+        ConvWindow w{bs(X), bs(X), X.H, (long long)X.rate * fr - X.H};
         for (int j = 0; j < c.n_resk; ++j) {
             const StreamTensor &P = st->P[i * c.n_resk + j], &Q = st->Q[i * c.n_resk + j];
             const float *cur = X.buf[p];
@@ -1289,6 +1306,85 @@ int stream_push(bvc_vocoder_stream *st, const float *d_mel, int k, float div, fl
 __global__ void tap_copy_kernel(const float *src, float *dst, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         dst[i] = src[i];
+}
+
+}  // namespace
+
+// ---- whole-hop streaming codec (BASELINE configs[4]) -----------------------------------------------------
+// B parallel streams, a fixed hop of new samples per tick; one tick = front-end of the frames the hop completes ->
+// BVRNN.encode (state carried) -> BVRNN.decode (state carried) -> incremental vocoder.  Everything a tick touches
+// lives at fixed device addresses and everything that changes from tick to tick (how many samples are buffered)
+// is DEVICE state, so a tick with k new frames and vocoder parity p is the same launch sequence every time: it is
+// captured once per (k, p) into a hipGraph and replayed.
+namespace {
+
+struct StreamDev { int fill; int pad_[3]; };             // samples buffered: sbuf[:, 0] is sample 256*F - 256, F = frames emitted
+
+__global__ __launch_bounds__(256) void sc_append_kernel(const StreamDev *__restrict__ st, const float *__restrict__ xin, int hop,
+                                                        float *__restrict__ sbuf, int cap) {
+    const int fill = st->fill;
+    float *d = sbuf + (long long)blockIdx.y * cap + fill;
+    const float *x = xin + (long long)blockIdx.y * hop;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < hop; i += gridDim.x * 256) d[i] = x[i];
+}
+// first tick only: samples -256..-1 of the reflect padding (meldataset.py:72-81): x[-i] = x[i]
+__global__ __launch_bounds__(256) void sc_reflect_left_kernel(float *__restrict__ sbuf, int cap, int pad) {
+    float *d = sbuf + (long long)blockIdx.x * cap;
+    for (int i = 1 + threadIdx.x; i <= pad; i += 256) d[pad - i] = d[pad + i];
+}
+__global__ __launch_bounds__(256) void sc_shift_kernel(const float *__restrict__ src, long long sstride, int soff,
+                                                       float *__restrict__ dst, long long dstride, int n) {
+    const float *a = src + (long long)blockIdx.y * sstride + soff;
+    float *d = dst + (long long)blockIdx.y * dstride;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = a[i];
+}
+__global__ void sc_advance_kernel(StreamDev *st, int delta) { if (threadIdx.x == 0) st->fill += delta; }
+
+}  // namespace
+
+struct bvc_stream_codec {
+    const bvc_model *m = nullptr;
+    int B = 0, hop = 0, kmax = 0, cap = 0;
+    float bits = 0.0f, scale = 1.0f, out_div = 1.0f;
+    int fill = 0;                       // host mirror of StreamDev::fill (same arithmetic)
+    int64_t frames = 0, ticks = 0;
+    bool first = true;
+    // device memory (one allocation)
+    char *pool = nullptr;
+    StreamDev *d_state = nullptr;
+    float *d_in = nullptr, *sbuf = nullptr, *stmp = nullptr, *mel = nullptr, *bitsbuf = nullptr, *codes = nullptr, *melhat = nullptr,
+          *wav = nullptr, *h_enc = nullptr, *h_dec = nullptr;
+    void *ws = nullptr; size_t ws_bytes = 0;
+    bvc_vocoder_stream *voc = nullptr;
+    hipGraphExec_t graph[8][2] = {};    // [k][vocoder parity]
+    bool use_graph = true;
+    ~bvc_stream_codec() {
+        for (auto &gk : graph) for (auto g : gk) if (g) (void)hipGraphExecDestroy(g);
+        if (voc) bvc_vocoder_stream_destroy(voc);
+        if (pool) (void)hipFree(pool);
+    }
+};
+
+namespace {
+
+// the launches of one tick with k new frames (k > 0), in stream order
+int stream_tick_body(bvc_stream_codec *st, int k, hipStream_t s) {
+    const bvc_model *m = st->m;
+    const int B = st->B;
+    int rc;
+    Workspace w;
+    if ((rc = check_ws(m, B, k, st->ws, st->ws_bytes, &w))) return rc;
+    // front-end on the sample buffer: frame j of this tick reads sbuf[:, 256 j : 256 j + 1024)
+    if ((rc = launch_stft_logmel(m->fe, st->sbuf, B, st->cap, k, 0, st->scale, st->mel, s))) return rc;
+    // drop the 256 k samples no later frame reads (through a scratch copy: the ranges overlap)
+    const int keep = st->cap - 256 * k;
+    sc_shift_kernel<<<dim3((unsigned)((keep + 255) / 256), B), 256, 0, s>>>(st->sbuf, st->cap, 256 * k, st->stmp, st->cap, keep);
+    sc_shift_kernel<<<dim3((unsigned)((keep + 255) / 256), B), 256, 0, s>>>(st->stmp, st->cap, 0, st->sbuf, st->cap, keep);
+    BVC_HIP_TRY(hipGetLastError());
+    if ((rc = run_encode(m, w, st->ws, st->mel, m->cfg.var_bit ? st->bitsbuf : nullptr, st->h_enc, B, k, st->codes, nullptr, st->h_enc,
+                         nullptr, s))) return rc;
+    if ((rc = run_decode(m, w, st->ws, st->codes, st->h_dec, B, k, st->melhat, st->h_dec, s))) return rc;
+    return bvc_vocoder_stream_push(st->voc, st->melhat, k, st->out_div, st->wav, s);
 }
 
 }  // namespace
@@ -1522,6 +1618,115 @@ int bvc_vocoder_stream_push(bvc_vocoder_stream *st, const float *d_mel, int32_t 
 #ifdef BVC_PHASE_PROBE
 int bvc_phase_probe_read(unsigned long long *out, int reset) { return bvc::phase_probe_read(out, reset); }
 #endif
+
+int bvc_stream_codec_create(const bvc_model *m, int32_t B, int32_t hop_samples, float bits_per_frame, float scale,
+                            float out_scale_div, bvc_stream_codec **out) {
+    if (!m || !out || B <= 0 || hop_samples <= 0) { set_error("bvc_stream_codec_create: bad arguments"); return BVC_EINVAL; }
+    const bvc_config &c = m->cfg;
+    if (hop_samples <= c.pad_left) { set_error("bvc_stream_codec_create: the hop must exceed the left reflect padding (%d samples)", c.pad_left); return BVC_EINVAL; }
+    std::unique_ptr<bvc_stream_codec> st(new bvc_stream_codec());
+    st->m = m; st->B = B; st->hop = hop_samples; st->bits = bits_per_frame; st->scale = scale; st->out_div = out_scale_div;
+    st->kmax = (hop_samples + c.hop - 1) / c.hop + 1;
+    if (st->kmax > 7) { set_error("bvc_stream_codec_create: hop too long (%d frames per tick)", st->kmax); return BVC_EINVAL; }
+    st->cap = c.n_fft + c.hop * st->kmax + hop_samples;
+    st->ws_bytes = bvc_workspace_bytes(m, B, st->kmax);
+    int spf = 1;                                             // samples per frame
+    for (int i = 0; i < c.n_up; ++i) spf *= c.up_rates[i];
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_state = take(sizeof(StreamDev)), o_in = take((size_t)B * hop_samples * 4), o_sbuf = take((size_t)B * st->cap * 4),
+                 o_stmp = take((size_t)B * st->cap * 4), o_mel = take((size_t)B * st->kmax * c.num_mels * 4),
+                 o_bits = take((size_t)B * st->kmax * 4), o_codes = take((size_t)B * st->kmax * c.z_dim * 4),
+                 o_melhat = take((size_t)B * st->kmax * c.num_mels * 4), o_wav = take((size_t)B * st->kmax * spf * 4),
+                 o_he = take((size_t)B * c.h_dim * 4), o_hd = take((size_t)B * c.h_dim * 4), o_ws = take(st->ws_bytes);
+    if (hipMalloc(reinterpret_cast<void **>(&st->pool), off) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("bvc_stream_codec_create: cannot allocate %zu bytes", off);
+        return BVC_ENOMEM;
+    }
+    BVC_HIP_TRY(hipMemset(st->pool, 0, off));
+    char *p = st->pool;
+    st->d_state = reinterpret_cast<StreamDev *>(p + o_state);
+    st->d_in = reinterpret_cast<float *>(p + o_in); st->sbuf = reinterpret_cast<float *>(p + o_sbuf); st->stmp = reinterpret_cast<float *>(p + o_stmp);
+    st->mel = reinterpret_cast<float *>(p + o_mel); st->bitsbuf = reinterpret_cast<float *>(p + o_bits); st->codes = reinterpret_cast<float *>(p + o_codes);
+    st->melhat = reinterpret_cast<float *>(p + o_melhat); st->wav = reinterpret_cast<float *>(p + o_wav);
+    st->h_enc = reinterpret_cast<float *>(p + o_he); st->h_dec = reinterpret_cast<float *>(p + o_hd); st->ws = p + o_ws;
+    int rc;
+    if ((rc = launch_fill(st->bitsbuf, bits_per_frame, (long long)B * st->kmax, nullptr))) return rc;
+    st->fill = c.pad_left;                                   // room for the left reflect padding of frame 0
+    StreamDev init{st->fill, {0, 0, 0}};
+    BVC_HIP_TRY(hipMemcpy(st->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
+    if ((rc = bvc_vocoder_stream_create(m, B, st->kmax, &st->voc))) return rc;
+    { const char *ng = getenv("BVC_STREAM_NO_GRAPH"); st->use_graph = !(ng && ng[0] == '1'); }
+    BVC_HIP_TRY(hipDeviceSynchronize());
+    *out = st.release();
+    return BVC_OK;
+}
+
+void bvc_stream_codec_destroy(bvc_stream_codec *st) { delete st; }
+
+int bvc_stream_codec_buffers(bvc_stream_codec *st, float **d_in, float **d_codes, float **d_wav, int32_t *max_frames_per_tick) {
+    if (!st) { set_error("null stream codec"); return BVC_EINVAL; }
+    if (d_in) *d_in = st->d_in;
+    if (d_codes) *d_codes = st->codes;
+    if (d_wav) *d_wav = st->wav;
+    if (max_frames_per_tick) *max_frames_per_tick = st->kmax;
+    return BVC_OK;
+}
+
+int bvc_stream_codec_tick(bvc_stream_codec *st, int32_t *n_frames, void *stream) {
+    if (!st) { set_error("null stream codec"); return BVC_EINVAL; }
+    const bvc_config &c = st->m->cfg;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = st->B;
+    // the hop joins the sample buffer (device-side fill level), frame 0's left reflect padding once the first samples are there
+    sc_append_kernel<<<dim3((unsigned)((st->hop + 255) / 256), B), 256, 0, s>>>(st->d_state, st->d_in, st->hop, st->sbuf, st->cap);
+    if (st->first) {
+        sc_reflect_left_kernel<<<dim3(B), 256, 0, s>>>(st->sbuf, st->cap, c.pad_left);
+        st->first = false;
+    }
+    BVC_HIP_TRY(hipGetLastError());
+    const int fill = st->fill + st->hop;
+    const int k = fill >= c.n_fft ? (fill - c.n_fft) / c.hop + 1 : 0;
+    if (k > st->kmax) { set_error("bvc_stream_codec_tick: internal frame count %d", k); return BVC_EINVAL; }
+    int rc = BVC_OK;
+    if (k > 0) {
+        const int parity = st->voc->parity;
+        const bool warm = st->use_graph && s != nullptr && st->frames >= STREAM_WARM_FRAMES;     // (the default stream cannot be captured)
+        g_stream_tick = true;
+        if (!warm) {
+            rc = stream_tick_body(st, k, s);
+        } else {
+            hipGraphExec_t &ge = st->graph[k][parity];
+            if (!ge) {                                       // first warm tick of this shape: capture it (the capture does not execute)
+                hipGraph_t graph = nullptr;
+                const int vp = st->voc->parity; const int64_t vf = st->voc->frames;
+                g_capturing = true;
+                hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+                if (e == hipSuccess) rc = stream_tick_body(st, k, s);
+                hipError_t e2 = (e == hipSuccess) ? hipStreamEndCapture(s, &graph) : e;
+                g_capturing = false;
+                st->voc->parity = vp; st->voc->frames = vf;  // the captured push advanced the host-side bookkeeping: undo, the replay redoes it
+                if (!rc && (e2 != hipSuccess || !graph)) { set_error("bvc_stream_codec_tick: hipGraph capture failed: %s", hipGetErrorString(e2)); rc = BVC_EHIP; }
+                if (!rc && hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0) != hipSuccess) { set_error("bvc_stream_codec_tick: hipGraphInstantiate failed"); rc = BVC_EHIP; }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            if (!rc) {
+                if (hipGraphLaunch(ge, s) != hipSuccess) { set_error("bvc_stream_codec_tick: hipGraphLaunch failed"); rc = BVC_EHIP; }
+                st->voc->parity ^= 1; st->voc->frames += k;  // what stream_push() does on the host side
+            }
+        }
+        g_stream_tick = false;
+        if (rc) return rc;
+    }
+    sc_advance_kernel<<<1, 64, 0, s>>>(st->d_state, st->hop - c.hop * k);
+    BVC_HIP_TRY(hipGetLastError());
+    st->fill = fill - c.hop * k;
+    st->frames += k;
+    st->ticks += 1;
+    if (n_frames) *n_frames = k;
+    return BVC_OK;
+}
 
 int bvc_model_status(const bvc_model *m, uint32_t *code) {
     if (!m) { set_error("null model"); return BVC_EINVAL; }

@@ -511,6 +511,11 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
     a.bs = win ? win->in_bs : L * c1.cin;
     a.row_begin = win ? win->row_begin : 0;
     a.t_origin = win ? win->t_origin : 0;
+    // streaming hops compute a few new rows behind a 64-row history: the 128 / 256-row tiles of the offline sweep would spend
+    // most of their MFMAs on rows nobody reads, so short windows take the smallest tile (4 waves x 16 rows)
+    const long long new_rows = L - a.row_begin;
+    if (win && c1.cin == 64 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<64, 1, 2, true>(a, B, s);
+    if (win && c1.cin == 32 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<32, 1, 3, true>(a, B, s);
     switch (c1.cin) {
         // tile shapes from a measured sweep (tools/voc_stage_times.py): MT = 16-row tiles per wave, OCC = workgroups per CU the
         // register budget is set for, ALIAS = the S2 tile re-uses the LDS of the S1 tile (one more barrier, half the LDS)

@@ -168,3 +168,65 @@ class StreamingDecoder:
             wav = self.m.vocoder(self.ctx, 10 ** 12, _scale_div=SCALING, _time_major=True)[:, 0]
             self.tail = wav[:, self.spf * self.ctx.shape[1]:]
         return self.tail[:, :max(0, n_extra)]
+
+
+class _DeviceView:
+    """Raw device memory owned by the library, exposed to torch through the CUDA array interface."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class StreamingCodec:
+    """BASELINE configs[4]: `batch` parallel streams, a fixed hop of new samples per tick, encode + decode of the frames
+    each hop completes in ONE library call (``bvc_stream_codec_tick``) that is replayed from a hipGraph once the
+    streams are warm.  State (sample buffer, both GRU states, the generator's activation history) lives in the library.
+
+    ``push(x)`` with x (batch, hop) returns (codes (batch, k, z_dim), wav (batch, 256 k)) for the k frames completed;
+    they equal the offline ``encode`` / ``decode`` of the whole signal on those frames (tests/test_gpu_streaming.py).
+    The returned tensors are views of the state's output buffers: valid until the next push."""
+
+    def __init__(self, model, batch, bitrate, hop=441, device=None):
+        eng = model.engine(None if device is None else torch.empty(0, device=device))
+        self.eng, self.B, self.hop = eng, batch, hop
+        self.dev = eng.device
+        self.z = model.conf["z_dim"]
+        self.spf = math.prod(model.conf["vocoder_config"]["upsample_rates"])
+        self.stream = torch.cuda.Stream(self.dev)          # a tick is captured into a hipGraph: not possible on the default stream
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.dev):
+            _abi.check(eng.lib.bvc_stream_codec_create(eng.handle, batch, hop, float(model.bits_per_frame(bitrate)), float(SCALING),
+                                                       float(SCALING), ctypes.byref(h)))
+        self.handle = h
+        pin, pc, pw, kmax = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int32()
+        _abi.check(eng.lib.bvc_stream_codec_buffers(h, ctypes.byref(pin), ctypes.byref(pc), ctypes.byref(pw), ctypes.byref(kmax)))
+        self.kmax = kmax.value
+        self._in = torch.as_tensor(_DeviceView(pin.value, (batch, hop)), device=self.dev)
+        self._codes_ptr, self._wav_ptr = pc.value, pw.value
+        self.frames = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.eng.lib.bvc_stream_codec_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    @torch.no_grad()
+    def push(self, x):
+        assert tuple(x.shape) == (self.B, self.hop)
+        cur = torch.cuda.current_stream(self.dev)
+        self.stream.wait_stream(cur)
+        k = ctypes.c_int32()
+        with torch.cuda.stream(self.stream), torch.cuda.device(self.dev):
+            self._in.copy_(x.to(self.dev, torch.float32), non_blocking=True)
+            _abi.check(self.eng.lib.bvc_stream_codec_tick(self.handle, ctypes.byref(k), ctypes.c_void_p(self.stream.cuda_stream)))
+        cur.wait_stream(self.stream)
+        k = k.value
+        self.frames += k
+        if k == 0:
+            return torch.empty(self.B, 0, self.z, device=self.dev), torch.empty(self.B, 0, device=self.dev)
+        codes = torch.as_tensor(_DeviceView(self._codes_ptr, (self.B, k, self.z)), device=self.dev)
+        wav = torch.as_tensor(_DeviceView(self._wav_ptr, (self.B, k * self.spf)), device=self.dev)
+        return codes, wav

@@ -163,6 +163,22 @@ int bvc_vocoder_stream_reset(bvc_vocoder_stream *st, void *stream);
 int bvc_vocoder_stream_push(bvc_vocoder_stream *st, const float *d_mel, int32_t k, float out_scale_div,
                             float *d_wav, void *stream);
 
+/* Whole-hop streaming codec (BASELINE.json configs[4]; not in the reference, which has no streaming mode): B parallel
+ * streams, `hop_samples` new samples per stream and tick (e.g. 441 = 20 ms).  A tick runs the front-end for the frames the
+ * hop completes (frame t needs samples up to 256 t + 768: 34.8 ms of look-ahead, README.md:19), BVRNN.encode and
+ * BVRNN.decode with carried GRU states and the incremental vocoder, i.e. encode + decode of exactly those frames, and equals
+ * the offline bvc_encode / bvc_decode of the whole signal on them.  The caller writes the hop into d_in (B, hop_samples)
+ * before the tick and finds d_codes (B, n_frames, z_dim) and d_wav (B, n_frames * 256) afterwards (buffers owned by the
+ * state, fixed addresses).  From the 33rd frame on a tick is replayed from a hipGraph captured on first use (one per
+ * frame count and vocoder parity; BVC_STREAM_NO_GRAPH=1 keeps eager launches).  scale / out_scale_div as in bvc_encode /
+ * bvc_decode.  One in-flight tick per state; create allocates, tick does not (except the graph instantiation). */
+typedef struct bvc_stream_codec bvc_stream_codec;
+int  bvc_stream_codec_create(const bvc_model *m, int32_t B, int32_t hop_samples, float bits_per_frame, float scale,
+                             float out_scale_div, bvc_stream_codec **out);
+void bvc_stream_codec_destroy(bvc_stream_codec *st);
+int  bvc_stream_codec_buffers(bvc_stream_codec *st, float **d_in, float **d_codes, float **d_wav, int32_t *max_frames_per_tick);
+int  bvc_stream_codec_tick(bvc_stream_codec *st, int32_t *n_frames, void *stream);
+
 /* BVRNNCodecModel.encode (bvrnn_codec_model.py:44-62): scale, log-mel, bits/frame =
  * bits_per_frame for every (b,t), zero initial state, BVRNN.encode.  d_wav (B,L) -> d_codes. */
 int bvc_encode(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, float scale,

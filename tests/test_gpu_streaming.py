@@ -143,3 +143,56 @@ def test_concurrent_stream_picker():
         torch.cuda.synchronize()
         assert all(float(b[0]) == 20.0 for b in bufs)
     assert len(bdist.concurrent_streams(2, dev)) == 2
+
+
+@pytest.mark.parametrize("B,graph", [(3, True), (40, True), (3, False)])
+def test_whole_hop_codec_equals_offline_and_oracle(model, B, graph, monkeypatch):
+    """bvc_stream_codec_tick (BASELINE configs[4]: 441-sample hops, the tick replayed from a hipGraph once warm) against
+    the offline path AND, directly, against the CPU oracle."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    from bvcodec.streaming import StreamingCodec
+    from oracle import codec as ocodec
+    if not graph:
+        monkeypatch.setenv("BVC_STREAM_NO_GRAPH", "1")
+    _, conf, vr, ge = make_model(True, 1024)
+    hop, hops = 441, 120                                            # 2.4 s: ~206 frames, > 170 of them replayed from graphs
+    L = hop * hops
+    x = synth.synthetic_speech(B, L, seed=23, kind="speech").to(DEV)
+    sc = StreamingCodec(model, B, 3000, hop=hop)
+    codes, wavs, ks = [], [], []
+    for i in range(hops):
+        c, w = sc.push(x[:, i * hop:(i + 1) * hop])
+        ks.append(c.shape[1])
+        codes.append(c.clone())
+        wavs.append(w.clone())
+    torch.cuda.synchronize()
+    codes, wav = torch.cat(codes, 1), torch.cat(wavs, 1)
+    F = codes.shape[1]
+    assert F == (L - 768) // 256 + 1 and set(ks) <= {0, 1, 2} and wav.shape[1] == 256 * F
+    # offline reference through the SAME recurrence kernels as the ticks (launch-per-layer schedule): bit-exact codes
+    ref_model = make_model(True, 1024, env={"BVC_RECURRENCE": "layers"})[0]
+    codes_off = ref_model.encode(x, 3000)
+    # (the hops never emit a frame that needs samples beyond L.)  Same kernels except phi_x / phi_z, which a hop runs frame by
+    # frame on the recurrent-layer kernel (other summation order than the all-frames GEMM): a bit may differ only at a tie
+    if not torch.equal(codes, codes_off[:, :F]):
+        from parity_stats import divergence_stats
+        mel = ref_model.mel_spectrogram(x)
+        bits = torch.full(mel.shape[:2], float(ref_model.bits_per_frame(3000)), device=DEV)
+        _, _, prob = ref_model.bvrnn.encode(mel, bits, torch.zeros(1, B, 1024, device=DEV), return_prob=True)
+        st = divergence_stats(codes.cpu(), codes_off[:, :F].cpu(), prob[:, :F].cpu(), int(ref_model.bits_per_frame(3000)))
+        assert st["max_first_divergence_margin"] < 1e-5, st
+    else:
+        wav_off = ref_model.decode(codes_off, L)
+        assert (wav - wav_off[:, :256 * F]).abs().max().item() <= 2e-6
+    # the oracle directly (2 utterances): free-running codes; waveform of the oracle decoding the streamed codes
+    torch.set_num_threads(16)
+    oc = ocodec.OracleCodec(conf, vr, ge)
+    r = oc.encode(x[:2].cpu(), 3000, full=True)
+    mism = codes[:2].cpu() != r["codes"][:, :F]
+    margin = (r["prob"][:, :F] - 0.5).abs()
+    assert not bool((mism & (margin > 1e-5)).any()), int(mism.sum())
+    if not bool(mism.any()):
+        ref_wav = oc.decode(r["codes"], L)[:, :256 * F]
+        assert float((wav[:2].cpu() - ref_wav).pow(2).mean().sqrt()) < 1e-4
+    model.check_status()
