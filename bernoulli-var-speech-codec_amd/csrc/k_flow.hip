@@ -15,7 +15,8 @@
 // layer's epilogue (bias, ELU, sigmoid/round/bit-mask, mel normalisation, GRU cell).  The MFMA computes
 // Y^T = W X^T (A = weight fragment, B = activation fragment) so that a lane's four results are four
 // consecutive features of one utterance: exactly the 16-byte granule of the next layer's operand block.
-// The next layer's first weight blocks are requested before the wait, so they travel meanwhile.
+// The next layer's first weight blocks are requested before the wait, so they travel meanwhile.  The layer sequence
+// is a compile-time program (bvrnn_flow_kernel<PERH, ENCODE>), its operands come from a device-resident FlowArgs.
 // Every wait is bounded: a wave that waits too long records it in the model's status word and stops
 // waiting for good (results are then garbage, the kernel still ends) - bvc_model_status() reports it.
 //
