@@ -98,6 +98,7 @@ struct bvc_model {
     bool use_flow = true;       // BVC_RECURRENCE=layers selects the launch-per-layer schedule instead
     int flow_perh = 0;          // k-blocks per wave of an h_dim-sized segment (0: h_dim not supported by the persistent kernel)
     unsigned *d_status = nullptr;       // sticky: set by a persistent kernel whose wait timed out
+    int cu_count = 0;                   // compute units of the device: a persistent launch needs one per workgroup
 
     ~bvc_model() {
         for (auto &g : graphs) { (void)hipGraphExecDestroy(g.exec1); (void)hipGraphExecDestroy(g.execN); if (g.idle) (void)hipEventDestroy(g.idle); }
@@ -835,6 +836,9 @@ int build_flow(bvc_model *m) {
     m->allocs.push_back(st);
     BVC_HIP_TRY(hipMemset(st, 0, 64));
     m->d_status = static_cast<unsigned *>(st);
+    int dev = 0;
+    BVC_HIP_TRY(hipGetDevice(&dev));
+    BVC_HIP_TRY(hipDeviceGetAttribute(&m->cu_count, hipDeviceAttributeMultiprocessorCount, dev));
     return flow_kernels_init();
 }
 
@@ -870,7 +874,16 @@ void flow_layers(const bvc_model *m, bool encode, FlowArgs *a) {
     a->hb = hb; a->zb = m->cfg.z_dim / 16; a->xb = m->cfg.num_mels / 16;
 }
 
-inline bool flow_usable(const bvc_model *m, int B) { return m->use_flow && !g_stream_tick && m->flow_perh > 0 && (B + 15) / 16 <= 4; }
+// The persistent kernel needs every one of its workgroups resident (they wait for each other) and a workgroup takes a whole
+// compute unit (8 waves x 256 VGPRs): utterance groups x feature tiles must not exceed the device's CU count (256 on MI355X:
+// up to 64 utterances at h_dim 1024).  Anything else takes the launch-per-layer schedule.
+inline bool flow_usable(const bvc_model *m, int B) {
+    if (!m->use_flow || g_stream_tick || m->flow_perh <= 0) return false;
+    const int H = m->cfg.h_dim, X = m->cfg.num_mels, Z = m->cfg.z_dim;
+    const int ntg = ((H > X ? (H > Z ? H : Z) : (X > Z ? X : Z)) / 16 + 7) / 8 * 8;
+    const int mt = (B + 15) / 16;
+    return ntg * mt <= m->cu_count;
+}
 
 inline float *flow_buf(const Workspace &w, int id, int parity) { return w.flow + (size_t)(id * 2 + parity) * w.flow_slot; }
 
