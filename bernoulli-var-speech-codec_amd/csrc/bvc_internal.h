@@ -180,7 +180,7 @@ struct FlowArgs {
 };
 int flow_kernels_init();
 int flow_perh(int h_dim);
-int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, hipStream_t s);
+int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, bool fill, hipStream_t s);
 int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s);
 
 // ------------------------------------------------------------------ front-end (k_frontend.hip)

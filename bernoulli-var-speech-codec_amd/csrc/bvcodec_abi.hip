@@ -939,7 +939,8 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, const float *d
         if (!ev) BVC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         if (g_flow_n[dev] >= (unsigned long long)tickets) BVC_HIP_TRY(hipStreamWaitEvent(s, ev, 0));
         ProbeScope probe(PK_LINEAR, s);
-        if ((rc = launch_flow(a, w.flow_args, m->flow_perh, encode, s))) return rc;
+        static const bool fill = !(getenv("BVC_FLOW_FILL") && getenv("BVC_FLOW_FILL")[0] == '0');
+        if ((rc = launch_flow(a, w.flow_args, m->flow_perh, encode, fill, s))) return rc;
         BVC_HIP_TRY(hipEventRecord(ev, s));
         ++g_flow_n[dev];
     }

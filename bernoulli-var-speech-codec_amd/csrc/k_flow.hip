@@ -187,6 +187,36 @@ __device__ __forceinline__ void gru_fetch_fresh(const FlowWg &g, unsigned buf, i
     } while (again);
 }
 
+// One filler quantum: acc += W[ntile rows][this wave's k-blocks] . X for an input that is complete and was verified by this very
+// wave earlier in the frame (no wait, no check).  GATE >= 0: gate-interleaved GRU weights, that gate only; GATE == -1: plain
+// packed weights; GATE == -2: no filler.  The operands are REQUESTED before a layer's reduction barrier and MULTIPLIED behind its
+// epilogue, i.e. while the inputs of the next layer are still being produced.
+struct FlowFill { const float *w; int wnb; int nb; unsigned buf; };
+template <int PER, int GATE>
+__device__ __forceinline__ bool fill_active(const FlowWg &g, const FlowFill &f) {
+    return GATE != -2 && g.ntile < f.nb && !(PER == 1 && g.wave >= f.nb);       // (these products have h_dim outputs and inputs)
+}
+template <int PER, int GATE>
+__device__ __forceinline__ void fill_issue(const FlowWg &g, const FlowFill &f, f32x4 (&wv)[PER], u32x4 (&xr)[PER]) {
+    if (!fill_active<PER, GATE>(g, f)) return;
+    const int kb0 = g.wave * PER;
+    const unsigned l16 = (unsigned)g.lane * 16u;
+    const GPtr ub = uniform_ptr(f.w, (GATE >= 0 ? ((size_t)g.ntile * f.wnb + kb0) * 3 + GATE : (size_t)g.ntile * f.wnb + kb0) * g.wmul);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) wv[u] = wload(ub, l16, GATE >= 0 ? u * 3 : u);
+    gru_issue_known<PER>(g, f.buf, f.nb, xr);
+}
+template <int PER, int GATE>
+__device__ __forceinline__ void fill_multiply(const FlowWg &g, const FlowFill &f, const f32x4 (&wv)[PER], const u32x4 (&xr)[PER], f32x4 &acc) {
+    if (!fill_active<PER, GATE>(g, f)) return;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const f32x4 xv = __builtin_bit_cast(f32x4, xr[u]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma16(wv[u][e], xv[e], acc);
+    }
+}
+
 __device__ __forceinline__ u32x4 publishable(f32x4 o, bool rowok) {
     u32x4 b = __builtin_bit_cast(u32x4, o);
 #pragma unroll
@@ -219,6 +249,9 @@ struct FlowCtx {
     bool rowok, give_up;
     bool probe;              // this lane records layer entry / exit times (bench instrumentation)
     unsigned hopctr;
+    // FILL: this wave's partial sums of the products whose inputs exist long before their layer - W_hh h, W_ih[:, H:] phi_z, the
+    // h half of dec.0 - computed one quantum at a time in the waits behind other layers
+    f32x4 fgh[3], fgi[3], fd0;
 };
 
 __device__ __forceinline__ void flow_stamp(const FlowCtx &c, int hopid, int which) {
@@ -230,15 +263,23 @@ __device__ __forceinline__ void flow_stamp(const FlowCtx &c, int hopid, int whic
 // One layer: y = epi( sum_s W_s . x_s + bias [+ addend] ).  PER k-blocks per wave and segment (compile time), one or
 // two segments (the one whose input is produced last comes last), PRE_IN: wv already holds segment 0's weights,
 // PRE_OUT: request `nxt`'s weights (PERN blocks per wave) into wn before the reduction.
-template <int PER, int EPI, bool TWO, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H = false>
+template <int PER, int EPI, bool TWO, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H = false, int FGATE = -2>
 __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin l0, int src0, const FlowLin l1, int src1,
-                                           int nb, int ntiles, int out, f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN]) {
+                                           int nb, int ntiles, int out, f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN],
+                                           const f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, const FlowFill fill = FlowFill{nullptr, 0, 0, 0u},
+                                           f32x4 *facc = nullptr) {
     const FlowWg &g = c.g;
     const auto &a = *c.a;
+    f32x4 fw[PERN];
+    u32x4 fx[PERN];
     if (g.ntile >= ntiles) {                               // uniform per workgroup (layers narrower than h_dim)
         if (PRE_OUT) {
 #pragma unroll
             for (int u = 0; u < PERN; ++u) wn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};      // defined on every path: no value lives across the layer
+        }
+        if (FGATE != -2) {                                 // nothing else to do in this layer: the whole quantum right away
+            fill_issue<PERN, FGATE>(g, fill, fw, fx);
+            fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc);
         }
         return;
     }
@@ -259,7 +300,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
             std4 = *reinterpret_cast<const f32x4 *>(a.stdv + n0);
         }
     }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = acc0;
     lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code);
     if (TWO) lin_segment<PER>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code);
     if (PRE_OUT) {                                         // the next layer's weights travel during the reduction and the wait
@@ -267,11 +308,13 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
     }
+    if (FGATE != -2) fill_issue<PERN, FGATE>(g, fill, fw, fx);
     float *r = c.red_lin + (c.hopctr & 1u) * 2048;
     ++c.hopctr;
     *reinterpret_cast<f32x4 *>(r + (wave * 64 + lane) * 4) = acc;
     __syncthreads();
     if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);                     // the publishing wave goes first: its SIMD partner may be multiplying a filler
         f32x4 v = *reinterpret_cast<const f32x4 *>(r + lane * 4);
 #pragma unroll
         for (int w = 1; w < 8; ++w) v += *reinterpret_cast<const f32x4 *>(r + (w * 64 + lane) * 4);
@@ -308,13 +351,15 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
         // The slot that will receive h(t+1) still holds h(t-1).  This layer's input was produced by workgroups that had all
         // consumed h(t), i.e. had all finished frame t-1: nobody reads h(t-1) any more (same tile shape as this layer's).
         if (REARM_H) __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, (unsigned)(FB_H * 2 + (c.par ^ 1u)) * a.slot_bytes + ytile, 0, AUX_SC1);
+        __builtin_amdgcn_s_setprio(0);
         flow_stamp(c, hopid, 1);
     }
+    if (FGATE != -2) fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc);
 }
 
 // GRU cell (PyTorch gate order r, z, n; bvrnn.py:206,227): gh = W_hh h, gi = W_ih [phi_x_gen ; phi_z]; in decode the
 // phi_z half of gi (+ b_ih) arrives pre-computed (a.part_gru).  Segments in the order their inputs become ready.
-template <int PER, bool ENCODE, int PERN>
+template <int PER, bool ENCODE, int PERN, bool FILL>
 __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const FlowLin nxt, f32x4 (&wn)[PERN]) {
     const FlowWg &g = c.g;
     const auto &a = *c.a;
@@ -332,14 +377,17 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
     flow_stamp(c, hopid, 0);
     f32x4 gi[3], gh[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { gi[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; gh[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int q = 0; q < 3; ++q) {
+        gi[q] = FILL ? c.fgi[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        gh[q] = FILL ? c.fgh[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     // h(t) and (encode) phi_z(z_t) are complete and were verified by this very wave earlier in the frame: their blocks are
     // requested at once and multiplied while phi_x(d_t), the input produced last, is still on its way
     // The weights stream through two register sets: the request for round i+1 is issued before round i is multiplied.
     if (!(PER == 1 && wave >= hb)) {                       // (wave-uniform) a wave without a k-block of its own contributes zeros
         constexpr int HALF = PER >= 4 ? PER / 4 : 1;       // k-blocks per round
         constexpr int RPS = PER / HALF;                    // rounds per segment
-        constexpr int NSEG = ENCODE ? 3 : 2;
+        constexpr int NSEG = FILL ? 1 : (ENCODE ? 3 : 2);  // FILL: the h and phi_z products were accumulated earlier in the frame
         constexpr int NR = NSEG * RPS;
         const int kb0 = wave * PER;
         const unsigned l16 = (unsigned)lane * 16u;
@@ -348,19 +396,20 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         const GPtr ux = uniform_ptr(a.w_ihx, ((size_t)g.ntile * 2 * hb + kb0) * 3 * g.wmul);
         u32x4 xa[PER], xb[PER];
         f32x4 wr[2][HALF][3];
-        gru_issue_w<HALF>(uh, l16, 0, wr[0]);
-        gru_issue_known<PER>(g, hbuf + c.par * a.slot_bytes, hb, xa);
-        if (ENCODE) gru_issue_known<PER>(g, (unsigned)(FB_Q3 * 2 + c.par) * a.slot_bytes, hb, xb);
+        gru_issue_w<HALF>(FILL ? ux : uh, l16, 0, wr[0]);
+        if (!FILL) gru_issue_known<PER>(g, hbuf + c.par * a.slot_bytes, hb, xa);
+        if (!FILL && ENCODE) gru_issue_known<PER>(g, (unsigned)(FB_Q3 * 2 + c.par) * a.slot_bytes, hb, xb);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int sg = i / RPS, h0 = (i % RPS) * HALF;
             if (i + 1 < NR) {
                 const int sn = (i + 1) / RPS, hn0 = ((i + 1) % RPS) * HALF;
-                gru_issue_w<HALF>(sn == 0 ? uh : ((ENCODE && sn == 1) ? uz : ux), l16, hn0, wr[(i + 1) & 1]);
+                gru_issue_w<HALF>(FILL ? ux : (sn == 0 ? uh : ((ENCODE && sn == 1) ? uz : ux)), l16, hn0, wr[(i + 1) & 1]);
             }
             if (i == (NSEG - 1) * RPS)                     // the last segment's input, phi_x(d_t): wait, fetch, verify
                 gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * a.slot_bytes, hb, xa, c.give_up, code);
-            if (sg == 0)                gru_round<PER, HALF>(wr[i & 1], xa, h0, gh);
+            if (FILL)                   gru_round<PER, HALF>(wr[i & 1], xa, h0, gi);
+            else if (sg == 0)           gru_round<PER, HALF>(wr[i & 1], xa, h0, gh);
             else if (ENCODE && sg == 1) gru_round<PER, HALF>(wr[i & 1], xb, h0, gi);
             else                        gru_round<PER, HALF>(wr[i & 1], xa, h0, gi);
         }
@@ -427,7 +476,7 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
 #ifndef BVC_FLOW_WAVES_PER_SIMD
 #define BVC_FLOW_WAVES_PER_SIMD 2
 #endif
-template <int PERH, bool ENCODE>
+template <int PERH, bool ENCODE, bool FILL>
 __global__ __launch_bounds__(512, BVC_FLOW_WAVES_PER_SIMD) void bvrnn_flow_kernel(const FlowArgs *a0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][8][256] layer partials | [8][6][256] GRU partials
     const int tid = threadIdx.x;
@@ -469,26 +518,46 @@ __global__ __launch_bounds__(512, BVC_FLOW_WAVES_PER_SIMD) void bvrnn_flow_kerne
         c.t = t;
         c.par = (unsigned)(t & 1);
         c.fr = (long long)c.row * T + t;
-        if (ENCODE) {
-            //         PER   epilogue  two    add    pre_in pre_out
-            flow_layer<PERH, FE_ELU,  false, true,  true,  true,  PERH>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb);
-            flow_layer<PERH, FE_ELU,  false, false, true,  false, PERH, true>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa);
-            flow_layer<PERH, FE_CODE, false, false, false, false, PERH>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb);
-            flow_layer<1,    FE_ELU,  false, false, false, true,  PERH>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa);
-            flow_layer<PERH, FE_ELU,  false, false, true,  true,  PERH>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb);
-            flow_layer<PERH, FE_ELU,  false, false, true,  true,  PERH>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa);
-            flow_layer<PERH, FE_ELU,  true,  false, true,  true,  PERH>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb);
-        } else {
-            flow_layer<PERH, FE_ELU,  false, true,  true,  true,  PERH>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb);
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        if (FILL) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { c.fgh[q] = zero4; c.fgi[q] = zero4; }
+            c.fd0 = zero4;
         }
-        if (ENCODE) flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa);
-        else        flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH, true>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa);
-        flow_layer<PERH, FE_ELU, false, false, true,  false, PERH>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb);
+        const unsigned hsrc = (unsigned)(FB_H * 2 + c.par) * a.slot_bytes, zsrc = (unsigned)(FB_Q3 * 2 + c.par) * a.slot_bytes;
+        // FILL: behind a layer, while its successors' inputs are still being produced, a wave multiplies one "quantum" of a product
+        // whose input has been complete since the start of the frame (h) or since phi_z (encode): the three gates of W_hh h, the
+        // h half of dec.0, the three gates of W_ih[:, H:] phi_z.  The GRU layer then only has phi_x(d_t)'s third left.
+        constexpr int G0 = FILL ? 0 : -2, G1 = FILL ? 1 : -2, G2 = FILL ? 2 : -2, GP = FILL ? -1 : -2;
+        const FlowFill f_hh = {a.w_hh, hb, hb, hsrc}, f_d0 = {a.dec0h.w, a.dec0h.wnb, hb, hsrc}, f_iz = {a.w_ihz, 2 * hb, hb, zsrc};
+        if (ENCODE) {
+            //         PER   epilogue  two    add    pre_in pre_out       rearm  filler
+            flow_layer<PERH, FE_ELU,  false, true,  true,  true,  PERH, false, G0>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb, zero4, f_hh, &c.fgh[0]);
+            flow_layer<PERH, FE_ELU,  false, false, true,  false, PERH, true,  G1>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa, zero4, f_hh, &c.fgh[1]);
+            flow_layer<PERH, FE_CODE, false, false, false, false, PERH, false, G2>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb, zero4, f_hh, &c.fgh[2]);
+            flow_layer<1,    FE_ELU,  false, false, false, true,  PERH, false, GP>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, zero4, f_d0, &c.fd0);
+            flow_layer<PERH, FE_ELU,  false, false, true,  true,  PERH>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb);
+            if (FILL) {
+                FlowLin d0 = L(a.dec0z);                   // dec.0: only the phi_z half is left; the bias travels with dec0h
+                d0.bias = a.dec0h.bias;
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, d0, wa);
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G0>(c, 7, d0, FB_Q3, d0, 0, hb, hb, FB_D1, wa, L(a.dec1), wb, c.fd0, f_iz, &c.fgi[0]);
+            } else {
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa);
+                flow_layer<PERH, FE_ELU, true,  false, true, true, PERH>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb);
+            }
+            flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH, false, G1>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_iz, &c.fgi[1]);
+            flow_layer<PERH, FE_ELU, false, false, true,  false, PERH, false, G2>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_iz, &c.fgi[2]);
+        } else {
+            flow_layer<PERH, FE_ELU, false, true,  true,  true,  PERH, false, G0>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, zero4, f_hh, &c.fgh[0]);
+            flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH, true,  G1>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_hh, &c.fgh[1]);
+            flow_layer<PERH, FE_ELU, false, false, true,  false, PERH, false, G2>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_hh, &c.fgh[2]);
+        }
         flow_layer<PERH, FE_MEL, false, false, false, false, PERH>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb);
         flow_layer<1,    FE_ELU, false, false, false, true,  PERH>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa);
         flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb);
         flow_layer<PERH, FE_ELU, false, false, true,  false, PERH>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa);
-        flow_gru<PERH, ENCODE, PERH>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa);
+        flow_gru<PERH, ENCODE, PERH, FILL>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa);
     }
 }
 
@@ -508,7 +577,8 @@ constexpr size_t FLOW_LDS = (2 * 8 * 256 + 8 * 6 * 256) * sizeof(float);      //
 
 template <int PERH, bool ENC>
 static int flow_attr() {
-    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<PERH, ENC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS));
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<PERH, ENC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS));
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<PERH, ENC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS));
     return BVC_OK;
 }
 
@@ -537,23 +607,25 @@ __global__ void flow_set_args_kernel(FlowArgs *dst, FlowArgs v) {
 }
 
 template <int PERH>
-static void flow_launch_t(const FlowArgs *d_a, bool encode, int grid, hipStream_t s) {
-    if (encode) hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, true>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
-    else        hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, false>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
+static void flow_launch_t(const FlowArgs *d_a, bool encode, bool fill, int grid, hipStream_t s) {
+    if (encode && fill)  hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, true, true>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
+    else if (encode)     hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, true, false>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
+    else if (fill)       hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, false, true>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
+    else                 hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, false, false>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
 }
 
 // d_args: device memory for a copy of `a` (read by the kernel through the scalar cache); it must stay untouched until the
 // launch has finished.
-int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, hipStream_t s) {
+int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, bool fill, hipStream_t s) {
     static_assert(sizeof(FlowArgs) % 4 == 0, "FlowArgs is copied in dwords");
     hipLaunchKernelGGL(flow_set_args_kernel, dim3(1), dim3(256), 0, s, d_args, a);
     const FlowArgs *d_a = d_args;
     const int grid = ((a.NTG + 7) / 8) * 8 * a.MT;
     switch (perh) {
-        case 1: flow_launch_t<1>(d_a, encode, grid, s); break;
-        case 2: flow_launch_t<2>(d_a, encode, grid, s); break;
-        case 4: flow_launch_t<4>(d_a, encode, grid, s); break;
-        case 8: flow_launch_t<8>(d_a, encode, grid, s); break;
+        case 1: flow_launch_t<1>(d_a, encode, fill, grid, s); break;
+        case 2: flow_launch_t<2>(d_a, encode, fill, grid, s); break;
+        case 4: flow_launch_t<4>(d_a, encode, fill, grid, s); break;
+        case 8: flow_launch_t<8>(d_a, encode, fill, grid, s); break;
         default: set_error("launch_flow: unsupported blocks per wave %d", perh); return BVC_EINVAL;
     }
     BVC_HIP_TRY(hipGetLastError());
