@@ -101,9 +101,9 @@ __device__ __forceinline__ f32x4 wload(GPtr ub, unsigned lane16, int blk) {
 // acc += W[ntile rows][segment] . X[segment]   for this wave's share of the segment's k-blocks
 template <int PER>
 __device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int wnb, int nb, unsigned buf, bool w_ready,
-                                            f32x4 (&wv)[PER], f32x4 &acc, bool &give_up, unsigned code) {
-    const int kb0 = g.wave * PER;
-    if (PER == 1 && g.wave >= nb) return;                  // wave-uniform: fewer k-blocks than waves
+                                            f32x4 (&wv)[PER], f32x4 &acc, bool &give_up, unsigned code, int kb_off = 0) {
+    const int kb0 = kb_off + g.wave * PER;
+    if (PER == 1 && kb0 >= nb) return;                     // wave-uniform: fewer k-blocks than waves
     if (!w_ready) {
         const GPtr ub = uniform_ptr(w, ((size_t)g.ntile * wnb + kb0) * g.wmul);
 #pragma unroll
@@ -263,7 +263,7 @@ __device__ __forceinline__ void flow_stamp(const FlowCtx &c, int hopid, int whic
 // One layer: y = epi( sum_s W_s . x_s + bias [+ addend] ).  PER k-blocks per wave and segment (compile time), one or
 // two segments (the one whose input is produced last comes last), PRE_IN: wv already holds segment 0's weights,
 // PRE_OUT: request `nxt`'s weights (PERN blocks per wave) into wn before the reduction.
-template <int PER, int EPI, bool TWO, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H = false, int FGATE = -2>
+template <int PER, int EPI, bool TWO, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H = false, int FGATE = -2, int NW = 8>
 __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin l0, int src0, const FlowLin l1, int src1,
                                            int nb, int ntiles, int out, f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN],
                                            const f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, const FlowFill fill = FlowFill{nullptr, 0, 0, 0u},
@@ -301,15 +301,20 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
         }
     }
     f32x4 acc = acc0;
-    lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code);
-    if (TWO) lin_segment<PER>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code);
+    if (PER == 1) {                                        // a narrow input (<= 8 k-blocks): one block per wave and pass
+        for (int off = 0; off < nb; off += NW)
+            lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, off);
+    } else {
+        lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code);
+        if (TWO) lin_segment<PER>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code);
+    }
     if (PRE_OUT) {                                         // the next layer's weights travel during the reduction and the wait
         const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
     }
     if (FGATE != -2) fill_issue<PERN, FGATE>(g, fill, fw, fx);
-    float *r = c.red_lin + (c.hopctr & 1u) * 2048;
+    float *r = c.red_lin + (c.hopctr & 1u) * (NW * 256);
     ++c.hopctr;
     *reinterpret_cast<f32x4 *>(r + (wave * 64 + lane) * 4) = acc;
     __syncthreads();
@@ -317,7 +322,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
         __builtin_amdgcn_s_setprio(3);                     // the publishing wave goes first: its SIMD partner may be multiplying a filler
         f32x4 v = *reinterpret_cast<const f32x4 *>(r + lane * 4);
 #pragma unroll
-        for (int w = 1; w < 8; ++w) v += *reinterpret_cast<const f32x4 *>(r + (w * 64 + lane) * 4);
+        for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4 *>(r + (w * 64 + lane) * 4);
         v += bias4;
         f32x4 o;
         if (EPI == FE_ELU) {
@@ -359,7 +364,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
 
 // GRU cell (PyTorch gate order r, z, n; bvrnn.py:206,227): gh = W_hh h, gi = W_ih [phi_x_gen ; phi_z]; in decode the
 // phi_z half of gi (+ b_ih) arrives pre-computed (a.part_gru).  Segments in the order their inputs become ready.
-template <int PER, bool ENCODE, int PERN, bool FILL>
+template <int PER, bool ENCODE, int PERN, bool FILL, int NW = 8>
 __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const FlowLin nxt, f32x4 (&wn)[PERN]) {
     const FlowWg &g = c.g;
     const auto &a = *c.a;
@@ -446,7 +451,7 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         for (int k = 0; k < 6; ++k) {
             v[k] = *reinterpret_cast<const f32x4 *>(red_gru + (k * 64 + lane) * 4);
 #pragma unroll
-            for (int w = 1; w < 8; ++w) v[k] += *reinterpret_cast<const f32x4 *>(red_gru + ((w * 6 + k) * 64 + lane) * 4);
+            for (int w = 1; w < NW; ++w) v[k] += *reinterpret_cast<const f32x4 *>(red_gru + ((w * 6 + k) * 64 + lane) * 4);
         }
         const f32x4 hp4 = __builtin_bit_cast(f32x4, hprev);
         f32x4 hn;
@@ -476,15 +481,15 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
 #ifndef BVC_FLOW_WAVES_PER_SIMD
 #define BVC_FLOW_WAVES_PER_SIMD 2
 #endif
-template <int PERH, bool ENCODE, bool FILL>
-__global__ __launch_bounds__(512, BVC_FLOW_WAVES_PER_SIMD) void bvrnn_flow_kernel(const FlowArgs *a0) {
+template <int PERH, bool ENCODE, bool FILL, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) void bvrnn_flow_kernel(const FlowArgs *a0) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][8][256] layer partials | [8][6][256] GRU partials
     const int tid = threadIdx.x;
     FlowCtx c;
     FlowArgsC ap = (FlowArgsC)(unsigned long long)a0;      // device-resident copy of the arguments (flow_set_args_kernel)
     c.a = ap;
     c.red_lin = lds;
-    c.red_gru = lds + 2 * 8 * 256;
+    c.red_gru = lds + 2 * NW * 256;
     c.g.lane = tid & 63;
     c.g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
@@ -532,32 +537,32 @@ __global__ __launch_bounds__(512, BVC_FLOW_WAVES_PER_SIMD) void bvrnn_flow_kerne
         const FlowFill f_hh = {a.w_hh, hb, hb, hsrc}, f_d0 = {a.dec0h.w, a.dec0h.wnb, hb, hsrc}, f_iz = {a.w_ihz, 2 * hb, hb, zsrc};
         if (ENCODE) {
             //         PER   epilogue  two    add    pre_in pre_out       rearm  filler
-            flow_layer<PERH, FE_ELU,  false, true,  true,  true,  PERH, false, G0>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb, zero4, f_hh, &c.fgh[0]);
-            flow_layer<PERH, FE_ELU,  false, false, true,  false, PERH, true,  G1>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa, zero4, f_hh, &c.fgh[1]);
-            flow_layer<PERH, FE_CODE, false, false, false, false, PERH, false, G2>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb, zero4, f_hh, &c.fgh[2]);
-            flow_layer<1,    FE_ELU,  false, false, false, true,  PERH, false, GP>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, zero4, f_d0, &c.fd0);
-            flow_layer<PERH, FE_ELU,  false, false, true,  true,  PERH>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb);
+            flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb, zero4, f_hh, &c.fgh[0]);
+            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, true, G1, NW>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa, zero4, f_hh, &c.fgh[1]);
+            flow_layer<PERH, FE_CODE, false, false, false, false, PERH, false, G2, NW>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb, zero4, f_hh, &c.fgh[2]);
+            flow_layer<1, FE_ELU, false, false, false, true, PERH, false, GP, NW>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, zero4, f_d0, &c.fd0);
+            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb);
             if (FILL) {
                 FlowLin d0 = L(a.dec0z);                   // dec.0: only the phi_z half is left; the bias travels with dec0h
                 d0.bias = a.dec0h.bias;
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, d0, wa);
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G0>(c, 7, d0, FB_Q3, d0, 0, hb, hb, FB_D1, wa, L(a.dec1), wb, c.fd0, f_iz, &c.fgi[0]);
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, d0, wa);
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G0, NW>(c, 7, d0, FB_Q3, d0, 0, hb, hb, FB_D1, wa, L(a.dec1), wb, c.fd0, f_iz, &c.fgi[0]);
             } else {
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa);
-                flow_layer<PERH, FE_ELU, true,  false, true, true, PERH>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb);
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa);
+                flow_layer<PERH, FE_ELU, true, false, true, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb);
             }
-            flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH, false, G1>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_iz, &c.fgi[1]);
-            flow_layer<PERH, FE_ELU, false, false, true,  false, PERH, false, G2>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_iz, &c.fgi[2]);
+            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_iz, &c.fgi[1]);
+            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_iz, &c.fgi[2]);
         } else {
-            flow_layer<PERH, FE_ELU, false, true,  true,  true,  PERH, false, G0>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, zero4, f_hh, &c.fgh[0]);
-            flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH, true,  G1>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_hh, &c.fgh[1]);
-            flow_layer<PERH, FE_ELU, false, false, true,  false, PERH, false, G2>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_hh, &c.fgh[2]);
+            flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, zero4, f_hh, &c.fgh[0]);
+            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, true, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_hh, &c.fgh[1]);
+            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_hh, &c.fgh[2]);
         }
-        flow_layer<PERH, FE_MEL, false, false, false, false, PERH>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb);
-        flow_layer<1,    FE_ELU, false, false, false, true,  PERH>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa);
-        flow_layer<PERH, FE_ELU, false, false, true,  true,  PERH>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb);
-        flow_layer<PERH, FE_ELU, false, false, true,  false, PERH>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa);
-        flow_gru<PERH, ENCODE, PERH, FILL>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa);
+        flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb);
+        flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa);
+        flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb);
+        flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, -2, NW>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa);
+        flow_gru<PERH, ENCODE, PERH, FILL, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa);
     }
 }
 
@@ -573,7 +578,8 @@ int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s) {
     return BVC_OK;
 }
 
-constexpr size_t FLOW_LDS = (2 * 8 * 256 + 8 * 6 * 256) * sizeof(float);      // 64 KiB
+constexpr size_t flow_lds(int nw) { return (size_t)(2 * nw * 256 + nw * 6 * 256) * sizeof(float); }      // 64 KiB with 8 waves
+constexpr size_t FLOW_LDS = flow_lds(8);
 
 template <int PERH, bool ENC>
 static int flow_attr() {
@@ -584,6 +590,7 @@ static int flow_attr() {
 
 int flow_kernels_init() {
     int rc;
+
     if ((rc = flow_attr<1, true>()) || (rc = flow_attr<1, false>()) || (rc = flow_attr<2, true>()) || (rc = flow_attr<2, false>()) ||
         (rc = flow_attr<4, true>()) || (rc = flow_attr<4, false>()) || (rc = flow_attr<8, true>()) || (rc = flow_attr<8, false>())) return rc;
     return BVC_OK;
@@ -616,11 +623,15 @@ static void flow_launch_t(const FlowArgs *d_a, bool encode, bool fill, int grid,
 
 // d_args: device memory for a copy of `a` (read by the kernel through the scalar cache); it must stay untouched until the
 // launch has finished.
+// (A 4-wave form - bvrnn_flow_kernel<16, ., false, 4>: one wave per SIMD, 214 VGPRs, so that the vocoder of the same or of
+// another call could share the CUs with the recurrence - was built and measured: correct, but 27 % slower per frame, and with
+// four batches in flight 5,120 audio-s/s against 5,700.  NW stays a template parameter; only the 8-wave form is instantiated.)
 int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, bool fill, hipStream_t s) {
     static_assert(sizeof(FlowArgs) % 4 == 0, "FlowArgs is copied in dwords");
     hipLaunchKernelGGL(flow_set_args_kernel, dim3(1), dim3(256), 0, s, d_args, a);
     const FlowArgs *d_a = d_args;
     const int grid = ((a.NTG + 7) / 8) * 8 * a.MT;
+
     switch (perh) {
         case 1: flow_launch_t<1>(d_a, encode, fill, grid, s); break;
         case 2: flow_launch_t<2>(d_a, encode, fill, grid, s); break;
