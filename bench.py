@@ -304,17 +304,26 @@ def main():
     if a.multi_streams > 1 and len(streams) == 1:
         # the same K steps with several independent batches in flight (throughput-oriented; results are bit-identical to the
         # serial schedule: tests/test_gpu_concurrency.py).  Timed like the headline (barrier + synchronize, max over ranks).
-        ms = pick_streams(a.multi_streams)
-        run(len(ms), ms)
-        dtm, _ = timed(a.steps, ms)
-        if use_pg:
-            tm = torch.tensor([dtm], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
-            dtm = float(tm.item())
-        out["multi_stream"] = {"value": round(world * B * a.seconds * a.steps / dtm, 2), "ms_per_step": round(1e3 * dtm / a.steps, 3),
-                               "streams": len(ms), "note": f"{len(ms)} x {B} utterances in flight per GPU, same steps round-robin on "
-                                                           f"{len(ms)} HIP streams"}
+        def multi():
+            ms = pick_streams(a.multi_streams)             # (settled with the schedule that is about to be timed)
+            run(len(ms), ms)
+            dt, _ = timed(a.steps, ms)
+            if use_pg:
+                tm = torch.tensor([dt], device=device, dtype=torch.float64)
+                torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+                dt = float(tm.item())
+            return {"value": round(world * B * a.seconds * a.steps / dt, 2), "ms_per_step": round(1e3 * dt / a.steps, 3)}
+
+        res = multi()                                      # default schedule: the persistent recurrences run one after the other
         model.check_status()
+        model.set_recurrence("layers")                     # throughput schedule: one launch per layer, the chains of the streams interleave
+        res_layers = multi()
+        model.set_recurrence("persistent")
+        out["multi_stream"] = dict(res, streams=a.multi_streams,
+                                   note=f"{a.multi_streams} x {B} utterances in flight per GPU, same steps round-robin on {a.multi_streams} HIP streams, default "
+                                        "(persistent) recurrence schedule",
+                                   layers_schedule=dict(res_layers, note="the same with model.set_recurrence('layers') (bvc_model_set_option "
+                                                                         "recurrence=1): one launch per layer, hipGraph-replayed"))
 
     if rank == 0 and not a.no_roofline:
         lib = _abi.load()

@@ -1742,6 +1742,17 @@ int bvc_stream_codec_tick(bvc_stream_codec *st, int32_t *n_frames, void *stream)
     return BVC_OK;
 }
 
+int bvc_model_set_option(bvc_model *m, const char *name, int32_t value) {
+    if (!m || !name) { set_error("bvc_model_set_option: null argument"); return BVC_EINVAL; }
+    if (strcmp(name, "recurrence") == 0) {                 // 0: persistent kernel (one batch at a time), 1: launch per layer
+        if (value != 0 && value != 1) { set_error("bvc_model_set_option: recurrence must be 0 or 1"); return BVC_EINVAL; }
+        m->use_flow = value == 0 && !m->side_branch;
+        return BVC_OK;
+    }
+    set_error("bvc_model_set_option: unknown option '%s'", name);
+    return BVC_EINVAL;
+}
+
 int bvc_model_status(const bvc_model *m, uint32_t *code) {
     if (!m) { set_error("null model"); return BVC_EINVAL; }
     unsigned v = 0;

@@ -101,6 +101,9 @@ class _Engine:
     def stream(self):
         return _abi.current_stream(self.device)
 
+    def set_option(self, name, value):
+        _abi.check(self.lib.bvc_model_set_option(self.handle, name.encode(), int(value)))
+
     def check_status(self):
         """Synchronises the device and raises if a persistent recurrence kernel of this model ever gave up waiting
         (its results were then invalid); see bvc_model_status in include/bvcodec.h."""
@@ -137,6 +140,16 @@ class _OnDevice(nn.Module):
             self._device = None
         return super()._apply(fn, *a, **k)
 
+    def set_recurrence(self, schedule):
+        """'persistent' (default): every frame of a call in one kernel launch - fastest for one batch at a time;
+        'layers': one launch per layer replayed from hipGraphs - more throughput when several batches are in flight on
+        several streams.  Applies to the engines created so far and to later ones.  Not while a call is in flight."""
+        if schedule not in ("persistent", "layers"):
+            raise ValueError("schedule must be 'persistent' or 'layers'")
+        self._recurrence = schedule
+        for eng in list(self._engines.values()):
+            eng.set_option("recurrence", 1 if schedule == "layers" else 0)
+
     def check_status(self):
         """Device-synchronising health check of the engines this module has created (bvc_model_status)."""
         for eng in list(self._engines.values()):
@@ -149,6 +162,8 @@ class _OnDevice(nn.Module):
         dev = _as_device(dev)
         if dev not in self._engines:
             self._engines[dev] = _Engine(self.conf, self._tensors, dev)
+            if getattr(self, "_recurrence", None) == "layers":
+                self._engines[dev].set_option("recurrence", 1)
         return self._engines[dev]
 
 

@@ -92,6 +92,12 @@ int  bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t 
                       bvc_model **out);
 void bvc_model_destroy(bvc_model *m);
 
+/* Run-time options of a model (not thread-safe; set them while no call is in flight).
+ *   "recurrence": 0 = the persistent recurrence kernel (default: fastest for one batch of up to 64 utterances at a time),
+ *                 1 = one launch per layer, hipGraph-replayed (more throughput when several batches are in flight on
+ *                     several streams; the start-up default follows BVC_RECURRENCE=layers). */
+int bvc_model_set_option(bvc_model *m, const char *name, int32_t value);
+
 /* The recurrence of BVRNN.encode / BVRNN.decode (bvrnn.py:186-206, 222-227) runs as ONE persistent kernel
  * whose workgroups hand activations to each other; every wait in it is bounded.  If a wait ever timed out
  * (a workgroup that never became resident), the kernel ends with invalid results and records it in the

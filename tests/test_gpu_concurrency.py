@@ -52,3 +52,34 @@ def test_many_workspaces_on_one_model():
     streams = [torch.cuda.Stream(DEV) for _ in range(12)]
     for codes, wav in _run(model, [x], L, streams, 24):
         assert torch.equal(codes, ref[0]) and torch.equal(wav, ref[1])
+
+
+def test_recurrence_schedule_can_be_switched_at_run_time():
+    """model.set_recurrence('layers' / 'persistent') (bvc_model_set_option): both schedules on one model, same weights; their
+    codes agree except where the probability sits within rounding noise of a tie (different summation orders)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_stats import divergence_stats
+    from gpu_common import make_model
+    from bvcodec import synth
+    model, conf, _, _ = make_model(True, 1024)
+    B, L = 32, 22050
+    x = synth.synthetic_speech(B, L, seed=77, kind="speech").to(DEV)
+    codes_p = model.encode(x, 3000)
+    wav_p = model.decode(codes_p, L)
+    try:
+        model.set_recurrence("layers")
+        codes_l = model.encode(x, 3000)
+        wav_l = model.decode(codes_p, L)                    # same codes in: the decoders must agree to rounding
+    finally:
+        model.set_recurrence("persistent")
+    assert (wav_l - wav_p).abs().max().item() < 1e-4
+    if not torch.equal(codes_l, codes_p):
+        mel = model.mel_spectrogram(x)
+        nb = int(model.bits_per_frame(3000))
+        bits = torch.full(mel.shape[:2], float(nb), device=DEV)
+        _, _, prob = model.bvrnn.encode(mel, bits, torch.zeros(1, B, 1024, device=DEV), return_prob=True)
+        st = divergence_stats(codes_l.cpu(), codes_p.cpu(), prob.cpu(), nb)
+        assert st["max_first_divergence_margin"] < 1e-5, st
+    assert torch.equal(model.encode(x, 3000), codes_p)       # and back
+    model.check_status()

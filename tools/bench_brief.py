@@ -9,6 +9,7 @@ for line in sys.stdin:
     d = json.loads(line)
     ms = d.get("multi_stream", {})
     rf = d.get("roofline", {})
-    print(f"value {d['value']} ({d['ms_per_step']} ms/step, streams {d['config']['streams']}) | multi_stream {ms.get('value')} "
+    ls = ms.get("layers_schedule", {})
+    print(f"value {d['value']} ({d['ms_per_step']} ms/step, streams {d['config']['streams']}) | multi_stream {ms.get('value')} / layers {ls.get('value')} "
           f"({ms.get('ms_per_step')} ms) | roofline frac {rf.get('frac')} rocprof {rf.get('frac_rocprof')} | "
           f"parity {d.get('parity', {}).get('code_bits_differing')} | {d['config']['workload'][:60]}")
