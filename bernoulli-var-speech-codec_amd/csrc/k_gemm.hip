@@ -526,50 +526,54 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
 // 36 floats so that the 16-byte fragment reads of 8 consecutive lanes cover all banks.  The k order seen
 // by each accumulator is the one of gemm_batched_kernel (16-blocks in order, k = 4*g + e inside), so both
 // produce the same bits.
-template <int ACT>
+// BM: rows per workgroup tile, 128 or 64 (the half-height form finishes the last, partly filled round of a launch: see
+// launch_gemm_batched); m_off: first row of this launch's tiles.
+template <int ACT, int BM>
 __global__ __launch_bounds__(256, 2) void gemm_batched_lds_kernel(const float *__restrict__ x, long long ldx,
                                                                   const float *__restrict__ w, long long ldw,
                                                                   const float *__restrict__ bias, int M, int N,
                                                                   int K, float *__restrict__ y, long long ldy,
-                                                                  long long frames_T, int mt16, int out_mode) {
+                                                                  long long frames_T, int mt16, int out_mode, int m_off) {
     constexpr int BK = 32, LDT = BK + 4;                 // floats per LDS row
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A 128xLDT | B 128xLDT]
+    constexpr int MI = BM / 32;                          // 16-row MFMA tiles per wave (waves: 2 along M x 2 along N)
+    constexpr int PA = BM / 32;                          // staging passes of 32 rows for the A operand
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A BMxLDT | B 128xLDT]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int mblk = blockIdx.y * 128, nblk = blockIdx.x * 128;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int mblk = m_off + blockIdx.y * BM, nblk = blockIdx.x * 128;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * 64;
 
-    // global staging: thread -> (row = tid/8 + 32*p, 16-byte piece tid%8) of the 128 x 32 stage of each operand
+    // global staging: thread -> (row = tid/8 + 32*p, 16-byte piece tid%8) of the BM x 32 / 128 x 32 stage of the operands
     const int srow = tid >> 3, spc = (tid & 7) * 4;
-    const float *xg[4], *wg[4];
+    const float *xg[PA], *wg[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < PA; ++p) {
         const int row = mblk + srow + 32 * p;
         xg[p] = x + (long long)(row < M ? row : M - 1) * ldx + spc;      // rows past M: re-read the last one, never stored
-        wg[p] = w + (long long)(nblk + srow + 32 * p) * ldw + spc;
     }
-    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int p = 0; p < 4; ++p) wg[p] = w + (long long)(nblk + srow + 32 * p) * ldw + spc;
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ga[4], gb[4];
+    constexpr int STAGE = (BM + 128) * LDT;              // floats per LDS buffer
+    f32x4 ga[PA], gb[4];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            ga[p] = *reinterpret_cast<const f32x4 *>(xg[p] + (long long)kt * BK);
-            gb[p] = *reinterpret_cast<const f32x4 *>(wg[p] + (long long)kt * BK);
-        }
+        for (int p = 0; p < PA; ++p) ga[p] = *reinterpret_cast<const f32x4 *>(xg[p] + (long long)kt * BK);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) gb[p] = *reinterpret_cast<const f32x4 *>(wg[p] + (long long)kt * BK);
     };
     auto park = [&](int buf) {
-        float *A = smem + buf * (2 * 128 * LDT), *B = A + 128 * LDT;
+        float *A = smem + buf * STAGE, *B = A + BM * LDT;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            *reinterpret_cast<f32x4 *>(A + (srow + 32 * p) * LDT + spc) = ga[p];
-            *reinterpret_cast<f32x4 *>(B + (srow + 32 * p) * LDT + spc) = gb[p];
-        }
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4 *>(A + (srow + 32 * p) * LDT + spc) = ga[p];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(B + (srow + 32 * p) * LDT + spc) = gb[p];
     };
     const int nk = K / BK;
     gload(0);
@@ -578,20 +582,19 @@ __global__ __launch_bounds__(256, 2) void gemm_batched_lds_kernel(const float *_
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) gload(kt + 1);
-        const float *A = smem + (kt & 1) * (2 * 128 * LDT) + (wm + r) * LDT + g * 4;
-        const float *B = smem + (kt & 1) * (2 * 128 * LDT) + 128 * LDT + (wn + r) * LDT + g * 4;
+        const float *A = smem + (kt & 1) * STAGE + (wm + r) * LDT + g * 4;
+        const float *B = smem + (kt & 1) * STAGE + BM * LDT + (wn + r) * LDT + g * 4;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            f32x4 av[4], bv[4];
+            f32x4 av[MI], bv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                av[i] = *reinterpret_cast<const f32x4 *>(A + i * 16 * LDT + h * 16);
-                bv[i] = *reinterpret_cast<const f32x4 *>(B + i * 16 * LDT + h * 16);
-            }
+            for (int i = 0; i < MI; ++i) av[i] = *reinterpret_cast<const f32x4 *>(A + i * 16 * LDT + h * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4 *>(B + i * 16 * LDT + h * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(av[i][e], bv[j][e], acc[i][j]);
         }
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void gemm_batched_lds_kernel(const float *_
         const int col = n0 + j * 16 + r;
         const float b = bias ? bias[col] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = m0 + i * 16 + g * 4 + e;
@@ -641,14 +644,32 @@ int launch_gemm_batched(const float *x, long long ldx, const float *w, long long
         const size_t lds = (size_t)2 * 2 * 128 * 36 * sizeof(float);
         static bool attr = false;
         if (!attr) {
-            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<0, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr = true;
         }
-        if (act == 1)
-            hipLaunchKernelGGL(gemm_batched_lds_kernel<1>, grid, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode);
-        else
-            hipLaunchKernelGGL(gemm_batched_lds_kernel<0>, grid, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode);
+        // Tail: 2 workgroups fit a CU, so the chip takes 512 tiles per round; a grid that ends with a partly filled round
+        // (configs[1]: 215 x 8 = 1,720 tiles = 3.36 rounds) pays a whole round for it.  The rows of that last round are
+        // computed with half-height tiles instead (a second launch; the same k order per accumulator, so the same bits).
+        static const bool no_tail = getenv("BVC_NO_GEMM_TAIL") != nullptr;
+        const int ncol = N / 128, rows_blk = (M + 127) / 128;
+        const int slots = 512, per_round = slots / ncol > 0 ? slots / ncol : 1;     // row blocks per full round
+        int full_blk = rows_blk;
+        if (!no_tail && rows_blk > per_round && rows_blk % per_round != 0 && (rows_blk % per_round) * 2 <= per_round)   // the half tiles fit ONE round
+            full_blk = (rows_blk / per_round) * per_round;
+        if (full_blk > 0) {
+            dim3 g1(ncol, full_blk);
+            if (act == 1) hipLaunchKernelGGL((gemm_batched_lds_kernel<1, 128>), g1, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, 0);
+            else          hipLaunchKernelGGL((gemm_batched_lds_kernel<0, 128>), g1, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, 0);
+        }
+        if (full_blk < rows_blk) {
+            const int m_off = full_blk * 128;
+            dim3 g2(ncol, (M - m_off + 63) / 64);
+            if (act == 1) hipLaunchKernelGGL((gemm_batched_lds_kernel<1, 64>), g2, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, m_off);
+            else          hipLaunchKernelGGL((gemm_batched_lds_kernel<0, 64>), g2, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, m_off);
+        }
         BVC_HIP_TRY(hipGetLastError());
         return BVC_OK;
     }
