@@ -213,6 +213,7 @@ struct ConvLayer {               // one causal conv as implicit GEMM on fp32 MFM
     int ks;                      // taps
     int dil;
     const float *wp;             // packed B fragments [ks][cin/4][ntiles][64]
+    const float *wp2;            // cin == cout == 8 only: two-output-rows-per-tile form [ks+1][2][64] (amp_pair8_kernel), else nullptr
     const float *bias;           // [cout] (for ConvT: bias replicated per phase)
     const float *act_a;          // exp(alpha) per input channel or nullptr (no input activation)
     const float *act_ib;         // 1/(exp(beta)+1e-9)
@@ -227,6 +228,7 @@ struct ConvWindow { long long in_bs, out_bs, row_begin, t_origin; };
 // in (B, Lin, cin) channels-last; out (B, Lout, cout).  Output row r reads input rows
 // r - (ks-1)*dil ... r  (rows outside [0,Lin) are zero).  res/acc have the layout of out.
 int conv_kernels_init();
+void set_amp8_enabled(bool on);  // C = 8 AMP pairs: two-rows-per-tile kernel (default) or the generic padded one
 int launch_snakebeta_test(const float *x, long long n, float a, float ib, float *y, hipStream_t s);
 int launch_conv_mfma(const ConvLayer &c, const float *in, long long Lin, float *out, long long Lout,
                      int B, int epi, const float *res, const float *acc, float divisor, hipStream_t s,

@@ -197,6 +197,19 @@ std::vector<float> pack_conv(const float *W, int cout, int cin, int ks) {
     return p;
 }
 
+// Conv1d weight W[8][8][ks] -> B fragments [ks+1][2][64] of the two-rows-per-tile form (k_vocoder.hip, amp_pair8_kernel):
+// column n = p*8 + co of k-step k holds W[co][ci][k - p] (zero outside the kernel)
+std::vector<float> pack_conv_two_rows(const float *W, int ks) {
+    std::vector<float> p((size_t)(ks + 1) * 2 * 64, 0.0f);
+    for (int k = 0; k <= ks; ++k)
+        for (int cg = 0; cg < 2; ++cg)
+            for (int l = 0; l < 64; ++l) {
+                const int n = l & 15, pr = n >> 3, co = n & 7, ci = cg * 4 + (l >> 4), j = k - pr;
+                if (j >= 0 && j < ks) p[((size_t)k * 2 + cg) * 64 + l] = W[((size_t)co * 8 + ci) * ks + j];
+            }
+    return p;
+}
+
 // ConvTranspose1d weight W[cin][cout][2u] -> 2-tap conv with u*cout columns (polyphase form)
 std::vector<float> convt_as_conv(const float *W, int cin, int cout, int u) {
     const int k = 2 * u, ncol = u * cout;
@@ -218,6 +231,8 @@ int make_conv(bvc_model *m, const float *W, const float *bias, int nbias_rep, in
     int rc;
     std::vector<float> wp = pack_conv(W, cout, cin, ks);
     if ((rc = upload(m, wp, &c->wp))) return rc;
+    c->wp2 = nullptr;
+    if (cin == 8 && cout == 8 && (rc = upload(m, pack_conv_two_rows(W, ks), &c->wp2))) return rc;
     std::vector<float> b((size_t)cout);
     const int per = cout / nbias_rep;
     for (int i = 0; i < cout; ++i) b[i] = bias[i % per];
@@ -1747,6 +1762,10 @@ int bvc_model_set_option(bvc_model *m, const char *name, int32_t value) {
     if (strcmp(name, "recurrence") == 0) {                 // 0: persistent kernel (one batch at a time), 1: launch per layer
         if (value != 0 && value != 1) { set_error("bvc_model_set_option: recurrence must be 0 or 1"); return BVC_EINVAL; }
         m->use_flow = value == 0 && !m->side_branch;
+        return BVC_OK;
+    }
+    if (strcmp(name, "vocoder_full_tiles") == 0) {         // 1 (default): C = 8 AMP pairs on the two-rows-per-tile kernel; 0: generic kernel.
+        set_amp8_enabled(value != 0);                      // Process-wide (a validation switch: both give the same bits)
         return BVC_OK;
     }
     set_error("bvc_model_set_option: unknown option '%s'", name);

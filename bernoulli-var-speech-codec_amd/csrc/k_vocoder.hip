@@ -383,6 +383,9 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     PHASE(1);
     if (ALIAS) __syncthreads();                            // every wave is done with S1(x): its LDS becomes t2
     for (int idx = tid; idx < (ks - 1) * S; idx += 256) t2[TR * S + idx] = 0.0f;    // spare rows read by discarded outputs
+    // local rows before `zrow` lie before the start of the signal: zero there (the reference pads AFTER the activation)
+    const long long zr64 = -(tbase + a.t_origin);
+    const int zrow = zr64 <= 0 ? 0 : (zr64 > TR ? TR : (int)zr64);
     if constexpr (C == 8) {
         // Only 8 of the tile's 16 columns exist: lanes r >= 8 hold padding.  They take over rows g*4+2, g*4+3 of
         // column r-8 from their neighbour 8 lanes down (DPP row_shr:8), so that every lane evaluates ONE SnakeBeta
@@ -397,8 +400,8 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
             const float v0 = r < 8 ? a0 : hi0, v1 = r < 8 ? a1 : hi1;
             const int row = mbase + i * 16 + g * 4 + e0;
             const f32x2 s2 = snakebeta2((f32x2){v0 + bias, v1 + bias}, splat2(aa), splat2(bb));
-            t2[row * S + col] = (tbase + row + a.t_origin >= 0) ? s2[0] : 0.0f;
-            t2[(row + 1) * S + col] = (tbase + row + 1 + a.t_origin >= 0) ? s2[1] : 0.0f;
+            t2[row * S + col] = row >= zrow ? s2[0] : 0.0f;
+            t2[(row + 1) * S + col] = row + 1 >= zrow ? s2[1] : 0.0f;
         }
     } else {
 #pragma unroll
@@ -413,8 +416,8 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
                         const int row = mbase + i * 16 + g * 4 + e;
                         const f32x2 u2 = (f32x2){acc[i][n][e] + bias, acc[i][n][e + 1] + bias};
                         const f32x2 s2 = snakebeta2(u2, splat2(aa), splat2(bb));
-                        t2[row * S + col] = (tbase + row + a.t_origin >= 0) ? s2[0] : 0.0f;
-                        t2[(row + 1) * S + col] = (tbase + row + 1 + a.t_origin >= 0) ? s2[1] : 0.0f;
+                        t2[row * S + col] = row >= zrow ? s2[0] : 0.0f;
+                        t2[(row + 1) * S + col] = row + 1 >= zrow ? s2[1] : 0.0f;
                     }
             }
         }
@@ -475,6 +478,272 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     PHASE(5);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The C = 8 stage (the last and longest signal: 256 rows per frame) on FULL MFMA tiles.  With eight channels a 16-column
+// tile of the kernel above is half padding.  Here the 16 columns are (p, co): output rows t and t + d (d = the conv's
+// dilation) side by side, p = 0 / 1.  Row t + p*d reads x[t + p*d - m*d] = x[t - (m - p)*d], so both rows read the same
+// ks + 1 input rows t - l*d, l = -1 .. ks-1, and the B matrix holds W_j in the p = 0 columns and W_(j-1) in the p = 1
+// columns of k-step j (zero where that runs off the kernel): (ks + 1) / (2 ks) of the MFMAs of the padded form, and every
+// lane of the SnakeBeta epilogue has work.  A column still accumulates its taps in the order j = 0 .. ks-1, input
+// channels ascending (the added zero products come first or last), so results equal the generic kernel's bit for bit.
+// Rows are paired inside blocks of 2d rows: pair m <-> rows R(m) + p*d, R(m) = (m / d) * 2d + m % d.  The LDS tiles are
+// stored de-interleaved to match: row rho = 2d*blk + half*d + i sits at position half * H + blk*d + i, which puts the A
+// operand of pair m, k-step k' = 2a + b at position m + a*d + b*H: lane stride = one row (S = 10 floats: conflict-free
+// ds_read_b32), one compile-time offset per k-step.
+static bool g_amp8_enabled = getenv("BVC_NO_AMP8") == nullptr;       // bvc_model_set_option("vocoder_full_tiles"): validation switch, process-wide
+void set_amp8_enabled(bool on) { g_amp8_enabled = on; }
+
+template <int D>
+__device__ __forceinline__ int pair_row(int m) { return (m / D) * (2 * D) + m % D; }
+template <int D>
+__device__ __forceinline__ int row_pos(int rho, int H) {
+    const int blk = rho / (2 * D), w = rho - blk * (2 * D);
+    return w >= D ? H + blk * D + (w - D) : blk * D + w;
+}
+template <int KS, int D, int MT2>
+struct Amp8Geom {
+    static constexpr int NP = 4 * MT2 * 16;                     // row pairs per conv phase and workgroup
+    static constexpr int NPE = (NP / D) * D;                    // pairs in whole blocks (conv1)
+    static constexpr int TR1 = 2 * NPE;                         // rows conv1 produces: [tbase, tbase + TR1)
+    static constexpr int TR = 2 * NP;                           // rows conv2 sweeps
+    static constexpr int TT = TR1 - (KS - 1);                   // valid output rows per workgroup
+    static constexpr int HALO1 = (KS - 1) * D;
+    static constexpr int ROWS1 = TR1 + HALO1;                   // S1(x) rows [tbase - HALO1, tbase + TR1)
+    static constexpr int H1 = NP + ((KS + 1) / 2) * D;          // half size of the S1(x) tile (positions)
+    static constexpr int H2 = NP + (KS + 1) / 2;                // half size of the S2(u) tile
+    static constexpr int S = 10;
+    static constexpr int LDS_ROWS = 2 * H1 > TR ? 2 * H1 : TR;  // (2 * H2 <= 2 * H1)
+    static constexpr size_t LDS_BYTES = (size_t)LDS_ROWS * S * sizeof(float);
+};
+
+// The kernel is persistent: a workgroup keeps both convs' weights, biases and SnakeBeta parameters in registers and walks
+// over tiles; the input rows of its NEXT tile are requested as soon as the registers that held the current ones are free
+// (after S1), so that their latency lies under the current tile's two convs instead of in front of every tile.
+template <int KS, int D, int MT2, int OCC>
+__global__ __launch_bounds__(256, OCC) void amp_pair8_kernel(AmpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using G = Amp8Geom<KS, D, MT2>;
+    constexpr int C = 8, S = G::S, NP = G::NP, NPE = G::NPE, TR = G::TR, TT = G::TT, H1 = G::H1, H2 = G::H2;
+    constexpr int NLD = (G::ROWS1 * 2 + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    // Workgroups are dealt round-robin to the 8 XCDs; neighbouring tiles share their halo rows, so each XCD takes a
+    // contiguous run of `per` tiles (the halo then hits in that XCD's L2) and its workgroups stride through the run.
+    const unsigned per = (a.ntile + 7u) >> 3, nli = gridDim.x >> 3;
+    const unsigned xcd = blockIdx.x & 7u;
+    unsigned li = blockIdx.x >> 3;
+    const unsigned run_end = (xcd + 1u) * per < a.ntile ? (xcd + 1u) * per : a.ntile;
+    if (xcd * per + li >= run_end) return;
+
+    float w1reg[KS + 1][2], w2reg[KS + 1][2];
+#pragma unroll
+    for (int k = 0; k <= KS; ++k)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            w1reg[k][q] = a.w1[(k * 2 + q) * 64 + lane];
+            w2reg[k][q] = a.w2[(k * 2 + q) * 64 + lane];
+        }
+    const f32x4 aa1 = *reinterpret_cast<const f32x4 *>(a.a1 + (tid & 1) * 4);      // phase 1: item idx has channels (idx & 1) * 4 ..; idx & 1 == tid & 1
+    const f32x4 bb1 = *reinterpret_cast<const f32x4 *>(a.ib1 + (tid & 1) * 4);
+    const int p = r >> 3, co = r & 7;
+    const float bias1 = a.b1[co], aa2 = a.a2[co], bb2 = a.ib2[co], bias2 = a.b2[co];
+
+    auto tile_origin = [&](unsigned bid, int &b, long long &t0) {
+        b = (int)(bid / (unsigned)a.tiles_per_batch);
+        t0 = a.row_begin + (long long)(bid - (unsigned)b * (unsigned)a.tiles_per_batch) * TT;
+    };
+    auto load_rows = [&](unsigned bid, f32x4 (&v)[NLD]) {       // x rows [t0 - (KS-1) - HALO1, .. + ROWS1) of tile bid
+        int b; long long t0;
+        tile_origin(bid, b, t0);
+        const float *xb = a.x + (long long)b * a.bs;
+        const long long tfirst = t0 - (KS - 1) - G::HALO1;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            const long long tg = tfirst + (idx >> 1);
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (idx < G::ROWS1 * 2 && tg >= 0 && tg < a.L) v[i] = *reinterpret_cast<const f32x4 *>(xb + tg * C + (idx & 1) * 4);
+        }
+    };
+
+    const int mbase = wave * MT2 * 16;
+    f32x4 acc[MT2];
+    // one conv on row pairs: KS + 1 k-steps of two MFMAs (input channels 0-3, 4-7); all offsets are compile-time
+    auto conv = [&](auto dd, int H, const float (&wreg)[KS + 1][2]) {
+        constexpr int DD = decltype(dd)::value;
+        const float *arow = lds + (mbase + r) * S + g;
+#pragma unroll
+        for (int i = 0; i < MT2; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k <= KS; ++k) {
+            const int pos = (k >> 1) * DD + (k & 1) * H;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float av[MT2];
+#pragma unroll
+                for (int i = 0; i < MT2; ++i) av[i] = arow[(pos + i * 16) * S + q * 4];
+#pragma unroll
+                for (int i = 0; i < MT2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wreg[k][q], acc[i], 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 v[NLD];
+    load_rows(xcd * per + li, v);
+    for (;;) {
+        const unsigned bid = xcd * per + li;
+        int b; long long t0;
+        tile_origin(bid, b, t0);
+        const long long tbase = t0 - (KS - 1);             // global row of conv1's local output row 0
+
+        // ---- phase 1: S1(x) rows [tbase - HALO1, tbase + TR1) into LDS, de-interleaved by D
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < G::ROWS1 * 2) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {                                        // S(0) = 0 keeps the zero padding
+                    const f32x2 o2 = snakebeta2((f32x2){v[i][e], v[i][e + 1]}, (f32x2){aa1[e], aa1[e + 1]}, (f32x2){bb1[e], bb1[e + 1]});
+                    o[e] = o2[0]; o[e + 1] = o2[1];
+                }
+                float2 *dst = reinterpret_cast<float2 *>(lds + row_pos<D>(idx >> 1, H1) * S + (idx & 1) * 4);
+                dst[0] = make_float2(o[0], o[1]);
+                dst[1] = make_float2(o[2], o[3]);
+            }
+        }
+        li += nli;
+        const bool more = xcd * per + li < run_end;        // (uniform)
+        if (more) load_rows(xcd * per + li, v);             // the next tile's rows travel under this tile's convs
+        __syncthreads();
+
+        // ---- phase 2: u = conv1(S1(x)); the tile of S2(u + b1) (de-interleaved by 1) takes over the LDS
+        conv(std::integral_constant<int, D>(), H1, w1reg);
+        __syncthreads();                                   // every wave is done with S1(x)
+        {
+            const long long zr64 = -(tbase + a.t_origin);  // local rows before zrow lie before the start of the signal: zero
+            const int zrow = zr64 <= 0 ? 0 : (zr64 > TR ? TR : (int)zr64);      // (the reference pads AFTER the activation)
+#pragma unroll
+            for (int i = 0; i < MT2; ++i) {
+                // pairs m .. m+3 of this lane: R(m) by one division, then stepped (R(m+1) = R(m) + 1, + D more when a block ends)
+                const int m0 = mbase + i * 16 + g * 4;
+                int rem = m0 % D, rowr = pair_row<D>(m0) + p * D;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const f32x2 s2 = snakebeta2((f32x2){acc[i][e] + bias1, acc[i][e + 1] + bias1}, splat2(aa2), splat2(bb2));
+                    const int row0 = rowr;
+                    rowr += rem == D - 1 ? D + 1 : 1; rem = rem == D - 1 ? 0 : rem + 1;
+                    const int row1 = rowr;
+                    rowr += rem == D - 1 ? D + 1 : 1; rem = rem == D - 1 ? 0 : rem + 1;
+                    const float v0 = row0 >= zrow ? s2[0] : 0.0f, v1 = row1 >= zrow ? s2[1] : 0.0f;
+                    if (NPE == NP || m0 + e < NPE) lds[row_pos<1>(row0, H2) * S + co] = v0;
+                    if (NPE == NP || m0 + e + 1 < NPE) lds[row_pos<1>(row1, H2) * S + co] = v1;
+                }
+            }
+            // rows conv1 did not produce ([TR1, TR + KS]): read only by discarded outputs, but keep them defined
+            for (int idx = tid; idx < (TR + KS + 1 - G::TR1) * C; idx += 256) {
+                const int row = G::TR1 + idx / C;
+                if (row_pos<1>(row, H2) < 2 * H2) lds[row_pos<1>(row, H2) * S + (idx % C)] = 0.0f;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3: x' = conv2(t2) + b2 + x (+ running sum, / num_kernels); operands requested before the MFMAs
+        const long long ob = (long long)b * a.bs + t0 * C;
+        constexpr int NLD3 = (TT * 2 + 255) / 256;
+        const long long rows_left = a.L - t0;
+        const int nvalid4 = (int)(rows_left < TT ? rows_left : TT) * 2;
+        f32x4 resq[NLD3], accq[NLD3];
+#pragma unroll
+        for (int i = 0; i < NLD3; ++i) {
+            const int idx = tid + i * 256;
+            const bool ok = idx < nvalid4;
+            resq[i] = ok ? reinterpret_cast<const f32x4 *>(a.x + ob)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            accq[i] = (ok && a.epi >= CE_RES_ACC) ? reinterpret_cast<const f32x4 *>(a.acc + ob)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        conv(std::integral_constant<int, 1>(), H2, w2reg);
+        __syncthreads();                                   // t2 is dead: the LDS now stages the output tile, row-major
+#pragma unroll
+        for (int i = 0; i < MT2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lds[(2 * (mbase + i * 16 + g * 4 + e) + p) * S + co] = acc[i][e] + bias2;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NLD3; ++i) {
+            const int idx = tid + i * 256;
+            if (idx >= nvalid4) continue;
+            const float2 lo = *reinterpret_cast<const float2 *>(lds + (idx >> 1) * S + (idx & 1) * 4);
+            const float2 hi = *reinterpret_cast<const float2 *>(lds + (idx >> 1) * S + (idx & 1) * 4 + 2);
+            f32x4 o4 = (f32x4){lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float o = o4[e] + resq[i][e];                            // x = xt + x      (models.py:119)
+                if (a.epi >= CE_RES_ACC) o = accq[i][e] + o;             // xs += resblock  (models.py:224)
+                if (a.epi == CE_RES_ACC_DIV) o = o / a.divisor;          // xs / num_kernels (models.py:225)
+                o4[e] = o;
+            }
+            reinterpret_cast<f32x4 *>(a.out + ob)[idx] = o4;
+        }
+        if (!more) break;
+        __syncthreads();                                   // the staging rows are read: the next tile's S1(x) may overwrite them
+    }
+}
+
+// workgroups of one instance the device holds at once (first call: conv_kernels_init, outside any stream capture)
+template <int KS, int D, int MT2, int OCC>
+static int amp8_slots() {
+    static int slots = 0;
+    if (!slots) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(amp_pair8_kernel<KS, D, MT2, OCC>), 256,
+                                                         Amp8Geom<KS, D, MT2>::LDS_BYTES) != hipSuccess) {
+            set_error("amp_pair8: occupancy query failed");
+            return -1;
+        }
+        slots = (per_cu > 0 ? per_cu : 1) * cus;
+    }
+    return slots;
+}
+template <int MT2, int OCC>
+static bool amp8_slots_all() {
+    return amp8_slots<3, 1, MT2, OCC>() > 0 && amp8_slots<3, 3, MT2, OCC>() > 0 && amp8_slots<3, 5, MT2, OCC>() > 0 &&
+           amp8_slots<7, 1, MT2, OCC>() > 0 && amp8_slots<7, 3, MT2, OCC>() > 0 && amp8_slots<7, 5, MT2, OCC>() > 0 &&
+           amp8_slots<11, 1, MT2, OCC>() > 0 && amp8_slots<11, 3, MT2, OCC>() > 0 && amp8_slots<11, 5, MT2, OCC>() > 0;
+}
+
+template <int KS, int D, int MT2, int OCC>
+static int launch_amp8_t(AmpArgs a, int B, hipStream_t s) {
+    using G = Amp8Geom<KS, D, MT2>;
+    a.tiles_per_batch = (int)((a.L - a.row_begin + G::TT - 1) / G::TT);
+    if (a.tiles_per_batch <= 0) return BVC_OK;
+    const int slots = amp8_slots<KS, D, MT2, OCC>();
+    if (slots <= 0) return BVC_EHIP;
+    ProbeScope probe(PK_CONV, s);
+    const unsigned ntile = (unsigned)(a.tiles_per_batch * (long long)B);
+    a.ntile = ntile;
+    const unsigned grid = ntile < (unsigned)slots ? ((ntile + 7u) & ~7u) : ((unsigned)slots & ~7u);
+    hipLaunchKernelGGL((amp_pair8_kernel<KS, D, MT2, OCC>), dim3(grid), dim3(256), G::LDS_BYTES, s, a);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+template <int MT2, int OCC>
+static int launch_amp8(AmpArgs a, int B, hipStream_t s) {
+    switch (a.ks * 8 + a.dil) {
+        case 3 * 8 + 1:  return launch_amp8_t<3, 1, MT2, OCC>(a, B, s);
+        case 3 * 8 + 3:  return launch_amp8_t<3, 3, MT2, OCC>(a, B, s);
+        case 3 * 8 + 5:  return launch_amp8_t<3, 5, MT2, OCC>(a, B, s);
+        case 7 * 8 + 1:  return launch_amp8_t<7, 1, MT2, OCC>(a, B, s);
+        case 7 * 8 + 3:  return launch_amp8_t<7, 3, MT2, OCC>(a, B, s);
+        case 7 * 8 + 5:  return launch_amp8_t<7, 5, MT2, OCC>(a, B, s);
+        case 11 * 8 + 1: return launch_amp8_t<11, 1, MT2, OCC>(a, B, s);
+        case 11 * 8 + 3: return launch_amp8_t<11, 3, MT2, OCC>(a, B, s);
+        case 11 * 8 + 5: return launch_amp8_t<11, 5, MT2, OCC>(a, B, s);
+        default: return -1;                                // not one of the generator's shapes: the generic kernel takes it
+    }
+}
+
 template <int C, int MT, int OCC, bool ALIAS>
 static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
     constexpr int TR = 4 * MT * 16;
@@ -516,6 +785,15 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
     const long long new_rows = L - a.row_begin;
     if (win && c1.cin == 64 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<64, 1, 2, true>(a, B, s);
     if (win && c1.cin == 32 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<32, 1, 3, true>(a, B, s);
+    if (c1.cin == 8 && c1.wp2 && c2.wp2 && g_amp8_enabled) {           // full-tile form of the C = 8 stage
+        AmpArgs a8 = a;
+        a8.w1 = c1.wp2; a8.w2 = c2.wp2;
+        // tile shapes from a measured sweep (16-pair tiles per wave x register budget): <2, 2> 2.07 ms per step for the stage,
+        // <2, 4> 2.17 (spills at ks = 11), <4, 4> 2.19, <1, 4> 2.4; the generic padded kernel 2.68.  Short streaming windows
+        // take the smallest tile (4 waves x 16 pairs = 128 rows).
+        const int rc8 = (win && new_rows <= 128) ? launch_amp8<1, 4>(a8, B, s) : launch_amp8<2, 2>(a8, B, s);
+        if (rc8 != -1) return rc8;
+    }
     switch (c1.cin) {
         // tile shapes from a measured sweep (tools/voc_stage_times.py): MT = 16-row tiles per wave, OCC = workgroups per CU the
         // register budget is set for, ALIAS = the S2 tile re-uses the LDS of the S1 tile (one more barrier, half the LDS)
@@ -576,6 +854,7 @@ int launch_snakebeta_test(const float *x, long long n, float a, float ib, float 
 
 int conv_kernels_init() {
     int rc;
+    if (!amp8_slots_all<1, 4>() || !amp8_slots_all<2, 2>()) return BVC_EHIP;
     if ((rc = allow_big_lds<128, 4, 2>())) return rc;
     if ((rc = allow_big_lds<80, 4, 2>())) return rc;
     if ((rc = allow_big_lds<64, 4, 2>())) return rc;

@@ -95,7 +95,10 @@ void bvc_model_destroy(bvc_model *m);
 /* Run-time options of a model (not thread-safe; set them while no call is in flight).
  *   "recurrence": 0 = the persistent recurrence kernel (default: fastest for one batch of up to 64 utterances at a time),
  *                 1 = one launch per layer, hipGraph-replayed (more throughput when several batches are in flight on
- *                     several streams; the start-up default follows BVC_RECURRENCE=layers). */
+ *                     several streams; the start-up default follows BVC_RECURRENCE=layers).
+ *   "vocoder_full_tiles": 1 (default) = the eight-channel generator stage runs on the kernel that packs two output rows into
+ *                 one MFMA tile, 0 = on the generic kernel (half of every tile is channel padding).  Same bits either way;
+ *                 a validation switch, and process-wide rather than per model. */
 int bvc_model_set_option(bvc_model *m, const char *name, int32_t value);
 
 /* The recurrence of BVRNN.encode / BVRNN.decode (bvrnn.py:186-206, 222-227) runs as ONE persistent kernel
