@@ -93,19 +93,21 @@ __device__ __forceinline__ f32x2 snakebeta2(f32x2 x, f32x2 a, f32x2 ib) {
     return x + q;
 }
 
-// CIN: input channels; NTW: 16-column tiles per workgroup; MT: 16-row tiles per wave.
-template <int CIN, int NTW, int MT>
+// CIN: input channels; NTW: 16-column tiles per wave; MT: 16-row tiles per wave.  The four waves of a workgroup split the
+// rows (each wave MT row tiles x the same NTW column tiles) or, NSPLIT, the columns (all waves the same MT row tiles, each its
+// own NTW column tiles): the second form is for streaming hops, whose one or two new frames are a handful of rows.
+template <int CIN, int NTW, int MT, bool NSPLIT = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     constexpr int S = CIN + 2;                 // LDS row stride (floats): (S/2) odd -> conflict-free
-    constexpr int TT = 4 * MT * 16;            // output rows per workgroup
+    constexpr int TT = (NSPLIT ? 1 : 4) * MT * 16;   // output rows per workgroup
     constexpr int C4 = CIN / 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.tiles_per_batch;
     const long long t0 = a.row_begin + (long long)(blockIdx.x % a.tiles_per_batch) * TT;
-    const int ntile0 = blockIdx.y * NTW;
+    const int ntile0 = NSPLIT ? (blockIdx.y * 4 + wave) * NTW : blockIdx.y * NTW;
     const int halo = (a.ks - 1) * a.dil;
     const int rows = TT + halo;
 
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int n = 0; n < NTW; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int mbase = wave * MT * 16;
+    const int mbase = NSPLIT ? 0 : wave * MT * 16;
     const float *wl = a.wp + (long long)ntile0 * 64 + lane;
     const long long kstride = (long long)a.ntiles * 64;          // floats per k-step in the packed weights
     bool nok[NTW];
@@ -805,16 +807,17 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
     }
 }
 
-template <int CIN, int NTW, int MT>
+template <int CIN, int NTW, int MT, bool NSPLIT = false>
 static int launch_one(const ConvArgs &a, int B, hipStream_t s) {
-    constexpr int TT = 4 * MT * 16;
+    constexpr int TT = (NSPLIT ? 1 : 4) * MT * 16;
     ConvArgs k = a;
     k.tiles_per_batch = (int)((a.Lout - a.row_begin + TT - 1) / TT);
     if (k.tiles_per_batch <= 0) return BVC_OK;
     const size_t lds = (size_t)(TT + (a.ks - 1) * a.dil) * (CIN + 2) * sizeof(float);
     if (lds > 160 * 1024) { set_error("conv tile needs %zu B of LDS", lds); return BVC_EINVAL; }
-    dim3 grid((unsigned)(k.tiles_per_batch * (long long)B), (unsigned)((a.ntiles + NTW - 1) / NTW));
-    auto kern = conv_mfma_kernel<CIN, NTW, MT>;
+    constexpr int NPW = NTW * (NSPLIT ? 4 : 1);            // column tiles per workgroup
+    dim3 grid((unsigned)(k.tiles_per_batch * (long long)B), (unsigned)((a.ntiles + NPW - 1) / NPW));
+    auto kern = conv_mfma_kernel<CIN, NTW, MT, NSPLIT>;
     ProbeScope probe(PK_CONV, s);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     BVC_HIP_TRY(hipGetLastError());
@@ -823,9 +826,9 @@ static int launch_one(const ConvArgs &a, int B, hipStream_t s) {
 
 // Allow > 64 KiB of dynamic LDS for every instantiation (called once from bvc_model_create, so the
 // compute entry points stay free of non-stream API calls).
-template <int CIN, int NTW, int MT>
+template <int CIN, int NTW, int MT, bool NSPLIT = false>
 static int allow_big_lds() {
-    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<CIN, NTW, MT>),
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_mfma_kernel<CIN, NTW, MT, NSPLIT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return BVC_OK;
 }
@@ -875,6 +878,16 @@ int launch_conv_mfma(const ConvLayer &c, const float *in, long long Lin, float *
     a.wp = c.wp; a.bias = c.bias; a.act_a = c.act_a; a.act_ib = c.act_ib;
     a.divisor = divisor; a.epi = epi; a.ks = c.ks; a.dil = c.dil; a.cout = c.cout; a.ntiles = c.ntiles;
     a.tiles_per_batch = 0;
+    // streaming hops: one or two new frames = at most 16 rows in front of the first two upsamplers; the row-split tiles (64 rows
+    // and more per workgroup) would compute mostly rows nobody reads, so the waves split the columns instead
+    if (win && Lout - a.row_begin <= 16) {
+        switch (c.cin) {
+            case 128: return launch_one<128, 4, 1, true>(a, B, s);
+            case 80:  return launch_one<80, 2, 1, true>(a, B, s);
+            case 64:  return launch_one<64, 4, 1, true>(a, B, s);
+            default: break;
+        }
+    }
     switch (c.cin) {
         case 128: return launch_one<128, 4, 2>(a, B, s);     // ConvT 128->8x64
         case 80:  return launch_one<80, 4, 2>(a, B, s);      // conv_pre 80->128
