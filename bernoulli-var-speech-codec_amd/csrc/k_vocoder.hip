@@ -224,7 +224,9 @@ __device__ unsigned long long g_phase[16];
 #else
 #define PHASE(i)
 #endif
-template <int C, int MT, int OCC, bool ALIAS>
+// NSPLIT (C = 64, streaming hops): the four waves split the COLUMN tiles and all work on the same MT row tiles
+// (a hop's one or two new frames are a handful of rows: row-split tiles would mostly compute rows nobody reads).
+template <int C, int MT, int OCC, bool ALIAS, bool NSPLIT = false>
 __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
 #ifdef BVC_PHASE_PROBE
     unsigned long long last_ = __builtin_readcyclecounter();
@@ -233,7 +235,9 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     constexpr int S = C + 2;
     constexpr int NT = (C + 15) / 16;
     constexpr int C4 = C / 4;
-    constexpr int TR = 4 * MT * 16;                       // rows computed by each conv phase
+    constexpr int TR = (NSPLIT ? 1 : 4) * MT * 16;        // rows computed by each conv phase
+    constexpr int NTL = NSPLIT ? NT / 4 : NT;             // column tiles of one wave
+    static_assert(!NSPLIT || (NT % 4 == 0 && C > 16), "NSPLIT needs four column tiles");
     constexpr int CGU = (C >= 64) ? 4 : (C4 % 8 == 0) ? 8 : (C4 % 4 == 0) ? 4 : 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -291,27 +295,28 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     __syncthreads();
     PHASE(0);
 
-    const int mbase = wave * MT * 16;
-    f32x4 acc[MT][NT];
+    const int mbase = NSPLIT ? 0 : wave * MT * 16;
+    const int nt0 = NSPLIT ? wave * NTL : 0;              // first column tile of this wave
+    f32x4 acc[MT][NTL];
     auto mma = [&](const float *tile, int d, const float *wp) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NTL; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // weight fragments of chunk q+1 are fetched while chunk q feeds the MFMAs
         const float *wl = wp + lane;
         constexpr int CPT = C4 / CGU;                       // chunks per tap
         const int nch = ks * CPT;
-        float bcur[CGU][NT], bnxt[CGU][NT];
-        auto loadb = [&](float (&dstb)[CGU][NT], int q) {
+        float bcur[CGU][NTL], bnxt[CGU][NTL];
+        auto loadb = [&](float (&dstb)[CGU][NTL], int q) {
             const float *wq = wl + (long long)q * CGU * NT * 64;      // packed [tap][cin/4][ntile][64] is chunk-linear
 #pragma unroll
             for (int u = 0; u < CGU; ++u)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) dstb[u][n] = wq[(u * NT + n) * 64];
+                for (int n = 0; n < NTL; ++n) dstb[u][n] = wq[(u * NT + nt0 + n) * 64];
         };
         // two register sets take turns (no copies): chunk q+1 is in flight while chunk q feeds the MFMAs
-        auto compute = [&](const float (&bw)[CGU][NT], int q) {
+        auto compute = [&](const float (&bw)[CGU][NTL], int q) {
             const int j = q / CPT, cg0 = (q - j * CPT) * CGU;
             const float *arow = tile + (mbase + r + j * d) * S + g;
 #pragma unroll
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n)
+                    for (int n = 0; n < NTL; ++n)
                         acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bw[u][n], acc[i][n], 0, 0, 0);
             }
         };
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
 #pragma unroll
             for (int u = 0; u < CGU; ++u)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) bcur[u][n] = bnxt[u][n];
+                for (int n = 0; n < NTL; ++n) bcur[u][n] = bnxt[u][n];
         }
     };
 
@@ -407,8 +412,8 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
         }
     } else {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int col = n * 16 + r;
+        for (int n = 0; n < NTL; ++n) {
+            const int col = (nt0 + n) * 16 + r;
             if (col < C) {
                 const float bias = a.b1[col], aa = a.a2[col], bb = a.ib2[col];
 #pragma unroll
@@ -450,8 +455,8 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     PHASE(4);
     if (ALIAS) __syncthreads();                            // t2 is dead: the same LDS now stages the output tile
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int col = n * 16 + r;
+    for (int n = 0; n < NTL; ++n) {
+        const int col = (nt0 + n) * 16 + r;
         if (col >= C) continue;
         const float bias = a.b2[col];
 #pragma unroll
@@ -746,9 +751,9 @@ static int launch_amp8(AmpArgs a, int B, hipStream_t s) {
     }
 }
 
-template <int C, int MT, int OCC, bool ALIAS>
+template <int C, int MT, int OCC, bool ALIAS, bool NSPLIT = false>
 static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
-    constexpr int TR = 4 * MT * 16;
+    constexpr int TR = (NSPLIT ? 1 : 4) * MT * 16;
     const int TT = TR - (a.ks - 1);
     a.tiles_per_batch = (int)((a.L - a.row_begin + TT - 1) / TT);
     if (a.tiles_per_batch <= 0) return BVC_OK;
@@ -760,9 +765,9 @@ static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
     a.ntile = ntile;
     {
         static bool attr = false;
-        if (!attr) { BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<C, MT, OCC, ALIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        if (!attr) { BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<C, MT, OCC, ALIAS, NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     }
-    hipLaunchKernelGGL((amp_pair_kernel<C, MT, OCC, ALIAS>), dim3((ntile + 7u) & ~7u), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((amp_pair_kernel<C, MT, OCC, ALIAS, NSPLIT>), dim3((ntile + 7u) & ~7u), dim3(256), lds, s, a);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }
@@ -785,6 +790,7 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
     // streaming hops compute a few new rows behind a 64-row history: the 128 / 256-row tiles of the offline sweep would spend
     // most of their MFMAs on rows nobody reads, so short windows take the smallest tile (4 waves x 16 rows)
     const long long new_rows = L - a.row_begin;
+    if (win && c1.cin == 64 && new_rows <= 32 - (c1.ks - 1)) return launch_amp_t<64, 2, 2, true, true>(a, B, s);      // 32 rows, waves split the columns
     if (win && c1.cin == 64 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<64, 1, 2, true>(a, B, s);
     if (win && c1.cin == 32 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<32, 1, 3, true>(a, B, s);
     if (c1.cin == 8 && c1.wp2 && c2.wp2 && g_amp8_enabled) {           // full-tile form of the C = 8 stage
