@@ -177,6 +177,7 @@ struct FlowArgs {
     unsigned long long *probe;              // bench only: [2][T][nodes] s_memrealtime stamps of workgroup 0 (layer entry / exit)
     int probe_nodes, probe_first;           // layers per frame, id of the first one
     int dbg_hot_w;                          // experiments only (BVC_FLOW_HOTW=1): every weight request hits the same blocks (wrong results)
+    int MG;                                 // utterance groups (chains) per workgroup; 1 = one chain (B <= 16 * CUs / feature tiles)
 };
 int flow_kernels_init();
 int flow_perh(int h_dim);

@@ -892,13 +892,22 @@ void flow_layers(const bvc_model *m, bool encode, FlowArgs *a) {
 // The persistent kernel needs every one of its workgroups resident (they wait for each other) and a workgroup takes a whole
 // compute unit (8 waves x 256 VGPRs): utterance groups x feature tiles must not exceed the device's CU count (256 on MI355X:
 // up to 64 utterances at h_dim 1024).  Anything else takes the launch-per-layer schedule.
-inline bool flow_usable(const bvc_model *m, int B) {
-    if (!m->use_flow || g_stream_tick || m->flow_perh <= 0) return false;
+// Larger batches interleave MG utterance groups ("chains") per workgroup (h_dim 1024 only; k_flow.hip, MULTI).
+constexpr int FLOW_MAX_CHAINS = 8;
+inline int flow_chains(const bvc_model *m, int B) {       // 0: not usable; else utterance groups per workgroup
+    if (!m->use_flow || g_stream_tick || m->flow_perh <= 0) return 0;
     const int H = m->cfg.h_dim, X = m->cfg.num_mels, Z = m->cfg.z_dim;
     const int ntg = ((H > X ? (H > Z ? H : Z) : (X > Z ? X : Z)) / 16 + 7) / 8 * 8;
     const int mt = (B + 15) / 16;
-    return ntg * mt <= m->cu_count;
+    const int slots = m->cu_count / ntg;                   // workgroups per feature tile that fit on the device
+    if (slots <= 0) return 0;
+    const int mg = (mt + slots - 1) / slots;
+    if (mg <= 1) return 1;
+    static const bool no_multi = getenv("BVC_FLOW_NO_CHAINS") != nullptr;
+    if (no_multi || m->flow_perh != 8 || mg > FLOW_MAX_CHAINS) return 0;
+    return mg;
 }
+inline bool flow_usable(const bvc_model *m, int B) { return flow_chains(m, B) > 0; }
 
 inline float *flow_buf(const Workspace &w, int id, int parity) { return w.flow + (size_t)(id * 2 + parity) * w.flow_slot; }
 
@@ -927,6 +936,7 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, const float *d
     a.flow = w.flow;
     a.slot_bytes = (unsigned)(w.flow_slot * sizeof(float));
     a.B = B; a.MT = mt16 / 16; a.T = T;
+    a.MG = flow_chains(m, B);
     a.NTG = (H > X ? (H > Z ? H : Z) : (X > Z ? X : Z)) / 16;
     a.part0 = w.part_dec0;
     a.part_gru = encode ? nullptr : w.part_gru;
@@ -955,7 +965,7 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, const float *d
         if (g_flow_n[dev] >= (unsigned long long)tickets) BVC_HIP_TRY(hipStreamWaitEvent(s, ev, 0));
         ProbeScope probe(PK_LINEAR, s);
         static const bool fill = !(getenv("BVC_FLOW_FILL") && getenv("BVC_FLOW_FILL")[0] == '0');
-        if ((rc = launch_flow(a, w.flow_args, m->flow_perh, encode, fill, s))) return rc;
+        if ((rc = launch_flow(a, w.flow_args, m->flow_perh, encode, fill && a.MG == 1, s))) return rc;
         BVC_HIP_TRY(hipEventRecord(ev, s));
         ++g_flow_n[dev];
     }

@@ -247,8 +247,10 @@ struct FlowCtx {
     long long t, fr;         // frame; (utterance, frame) index of this lane's row
     int row;
     bool rowok, give_up;
+    bool pre_now;            // MULTI: the next layer's weights are requested by the LAST chain of a layer only (true otherwise)
     bool probe;              // this lane records layer entry / exit times (bench instrumentation)
     unsigned hopctr;
+    unsigned gructr;         // MULTI: GRU calls so far (slot of the GRU partial sums); 0 otherwise
     // FILL: this wave's partial sums of the products whose inputs exist long before their layer - W_hh h, W_ih[:, H:] phi_z, the
     // h half of dec.0 - computed one quantum at a time in the waits behind other layers
     f32x4 fgh[3], fgi[3], fd0;
@@ -258,6 +260,55 @@ __device__ __forceinline__ void flow_stamp(const FlowCtx &c, int hopid, int whic
     if (!c.probe) return;
     const auto &a = *c.a;
     a.probe[((long long)which * a.T + c.t) * a.probe_nodes + (hopid - a.probe_first)] = __builtin_amdgcn_s_memrealtime();
+}
+
+// Wave 0 of a workgroup, after the barrier: sum the waves' partial tiles (fixed order), apply the layer's epilogue and publish the
+// 1 KiB block; re-arm (poison) this workgroup's block of the other frame parity.
+template <int EPI, bool ADD, bool REARM_H, int NW>
+__device__ __forceinline__ void flow_publish(const FlowCtx &c, int hopid, const float *r, int n0, unsigned ytile, int ntiles, int out,
+                                             const f32x4 bias4, const f32x4 add4, const f32x4 mean4, const f32x4 std4, float bitsv) {
+    const FlowWg &g = c.g;
+    const auto &a = *c.a;
+    const int lane = g.lane;
+    __builtin_amdgcn_s_setprio(3);                     // the publishing wave goes first: its SIMD partner may be multiplying a filler
+    f32x4 v = *reinterpret_cast<const f32x4 *>(r + lane * 4);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4 *>(r + (w * 64 + lane) * 4);
+    v += bias4;
+    f32x4 o;
+    if (EPI == FE_ELU) {
+        if (ADD) v += add4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = elu1(v[j]);
+    } else if (EPI == FE_CODE) {                       // bvrnn.py:189-194
+        f32x4 pr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pr[j] = sigmoid1(v[j]);
+            float z = rintf(pr[j]);                    // round half to even (torch.round)
+            if (a.var_bit) z = (bitsv > (float)(n0 + j)) ? z : 0.5f;
+            o[j] = z;
+        }
+        if (c.rowok) {
+            *reinterpret_cast<f32x4 *>(a.codes + c.fr * (ntiles * 16) + n0) = o;
+            if (a.prob) *reinterpret_cast<f32x4 *>(a.prob + c.fr * (ntiles * 16) + n0) = pr;
+        }
+    } else {                                           // FE_MEL, bvrnn.py:202-204
+        if (a.mel && c.rowok) *reinterpret_cast<f32x4 *>(a.mel + c.fr * (ntiles * 16) + n0) = v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean4[j]) / std4[j];
+    }
+    unsigned pv = FLOW_POISON;
+    asm volatile("" : "+v"(pv));                       // re-materialised here (hoisted out of the frame loop it gets spilled)
+    const u32x4 poison4 = {pv, pv, pv, pv};
+    const unsigned ob = (unsigned)(out * 2) * a.slot_bytes;
+    __builtin_amdgcn_raw_buffer_store_b128(publishable(o, c.rowok), g.rs, ob + c.par * a.slot_bytes + ytile, 0, AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, ob + (c.par ^ 1u) * a.slot_bytes + ytile, 0, AUX_SC1);
+    // The slot that will receive h(t+1) still holds h(t-1).  This layer's input was produced by workgroups that had all
+    // consumed h(t), i.e. had all finished frame t-1: nobody reads h(t-1) any more (same tile shape as this layer's).
+    if (REARM_H) __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, (unsigned)(FB_H * 2 + (c.par ^ 1u)) * a.slot_bytes + ytile, 0, AUX_SC1);
+    __builtin_amdgcn_s_setprio(0);
+    flow_stamp(c, hopid, 1);
 }
 
 // One layer: y = epi( sum_s W_s . x_s + bias [+ addend] ).  PER k-blocks per wave and segment (compile time), one or
@@ -273,7 +324,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
     f32x4 fw[PERN];
     u32x4 fx[PERN];
     if (g.ntile >= ntiles) {                               // uniform per workgroup (layers narrower than h_dim)
-        if (PRE_OUT) {
+        if (PRE_OUT && c.pre_now) {
 #pragma unroll
             for (int u = 0; u < PERN; ++u) wn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};      // defined on every path: no value lives across the layer
         }
@@ -308,7 +359,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
         lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code);
         if (TWO) lin_segment<PER>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code);
     }
-    if (PRE_OUT) {                                         // the next layer's weights travel during the reduction and the wait
+    if (PRE_OUT && c.pre_now) {                            // the next layer's weights travel during the reduction and the wait
         const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
@@ -318,48 +369,108 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
     ++c.hopctr;
     *reinterpret_cast<f32x4 *>(r + (wave * 64 + lane) * 4) = acc;
     __syncthreads();
-    if (wave == 0) {
-        __builtin_amdgcn_s_setprio(3);                     // the publishing wave goes first: its SIMD partner may be multiplying a filler
-        f32x4 v = *reinterpret_cast<const f32x4 *>(r + lane * 4);
-#pragma unroll
-        for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4 *>(r + (w * 64 + lane) * 4);
-        v += bias4;
-        f32x4 o;
-        if (EPI == FE_ELU) {
-            if (ADD) v += add4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = elu1(v[j]);
-        } else if (EPI == FE_CODE) {                       // bvrnn.py:189-194
-            f32x4 pr;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                pr[j] = sigmoid1(v[j]);
-                float z = rintf(pr[j]);                    // round half to even (torch.round)
-                if (a.var_bit) z = (bitsv > (float)(n0 + j)) ? z : 0.5f;
-                o[j] = z;
-            }
-            if (c.rowok) {
-                *reinterpret_cast<f32x4 *>(a.codes + c.fr * (ntiles * 16) + n0) = o;
-                if (a.prob) *reinterpret_cast<f32x4 *>(a.prob + c.fr * (ntiles * 16) + n0) = pr;
-            }
-        } else {                                           // FE_MEL, bvrnn.py:202-204
-            if (a.mel && c.rowok) *reinterpret_cast<f32x4 *>(a.mel + c.fr * (ntiles * 16) + n0) = v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean4[j]) / std4[j];
-        }
-        unsigned pv = FLOW_POISON;
-        asm volatile("" : "+v"(pv));                       // re-materialised here (hoisted out of the frame loop it gets spilled)
-        const u32x4 poison4 = {pv, pv, pv, pv};
-        const unsigned ob = (unsigned)(out * 2) * a.slot_bytes;
-        __builtin_amdgcn_raw_buffer_store_b128(publishable(o, c.rowok), g.rs, ob + c.par * a.slot_bytes + ytile, 0, AUX_SC1);
-        __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, ob + (c.par ^ 1u) * a.slot_bytes + ytile, 0, AUX_SC1);
-        // The slot that will receive h(t+1) still holds h(t-1).  This layer's input was produced by workgroups that had all
-        // consumed h(t), i.e. had all finished frame t-1: nobody reads h(t-1) any more (same tile shape as this layer's).
-        if (REARM_H) __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, (unsigned)(FB_H * 2 + (c.par ^ 1u)) * a.slot_bytes + ytile, 0, AUX_SC1);
-        __builtin_amdgcn_s_setprio(0);
-        flow_stamp(c, hopid, 1);
-    }
+    if (wave == 0) flow_publish<EPI, ADD, REARM_H, NW>(c, hopid, r, n0, ytile, ntiles, out, bias4, add4, mean4, std4, bitsv);
     if (FGATE != -2) fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc);
+}
+
+// MULTI: one single-segment layer for ALL chains of this workgroup, software-pipelined across the chains: while chain ci is
+// multiplied, reduced and published, the operand blocks of chain ci+1 are already on their way (fetched without a flag poll -
+// their producers published them while this workgroup was busy with other chains - and verified like every fetch; a block
+// that still holds the sentinel sends the wave through the ordinary wait-and-fetch path).  Same arithmetic, same order per
+// output as flow_layer.
+template <int PER, int EPI, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H, int NW>
+__device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const FlowLin l0, int src0, int nb, int ntiles, int out,
+                                                  f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN], int mt0, int nch, long long T) {
+    static_assert(PER > 1, "narrow inputs take the per-chain path");
+    FlowWg &g = c.g;
+    const auto &a = *c.a;
+    if (g.ntile >= ntiles) {
+        if (PRE_OUT) {
+#pragma unroll
+            for (int u = 0; u < PERN; ++u) wn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+    const int lane = g.lane, wave = g.wave;
+    const unsigned code = (unsigned)((c.t << 4) | (unsigned)hopid) | 0x80000000u;
+    const int n0 = g.ntile * 16 + (lane >> 4) * 4;
+    const int kb0 = wave * PER;
+    const unsigned bufb = (unsigned)(src0 * 2 + c.par) * a.slot_bytes;
+    if (!PRE_IN) {
+        const GPtr ub = uniform_ptr(l0.w, ((size_t)g.ntile * l0.wnb + kb0) * g.wmul);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) wv[u] = wload(ub, (unsigned)lane * 16u, u);
+    }
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, mean4 = {0.f, 0.f, 0.f, 0.f}, std4 = {1.f, 1.f, 1.f, 1.f};
+    if (wave == 0) {
+        if (l0.bias) bias4 = *reinterpret_cast<const f32x4 *>(l0.bias + n0);
+        if (EPI == FE_MEL) {
+            mean4 = *reinterpret_cast<const f32x4 *>(a.mean + n0);
+            std4 = *reinterpret_cast<const f32x4 *>(a.stdv + n0);
+        }
+    }
+    unsigned spins = 0;
+    g.mtile = mt0;
+    flow_stamp(c, hopid, 0);
+    FlowSrc s = flow_wait<PER>(g, bufb, nb, kb0, c.give_up, code, spins);      // the first chain: wait for its producers
+    u32x4 xc[PER], xn[PER];
+    flow_issue<PER>(g, s, xc);
+    for (int ci = 0; ci < nch; ++ci) {
+        const bool last = ci == nch - 1;
+        g.mtile = mt0 + ci;
+        c.row = g.mtile * 16 + (lane & 15);
+        c.rowok = c.row < a.B;
+        c.fr = (long long)c.row * T + c.t;
+        if (!last) {                                       // the next chain's blocks: requested before this chain's are waited for
+            FlowSrc sn;
+            sn.base = __builtin_amdgcn_readfirstlane(bufb + (unsigned)((g.mtile + 1) * nb + kb0) * 1024u);
+            sn.vl = (unsigned)lane * 16u;
+            flow_issue<PER>(g, sn, xn);
+        } else {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) xn[u] = (u32x4){0u, 0u, 0u, 0u};
+        }
+        const unsigned ytile = (unsigned)((g.mtile * ntiles + g.ntile) * 1024 + lane * 16);
+        f32x4 add4 = {0.f, 0.f, 0.f, 0.f};
+        float bitsv = 0.0f;
+        if (wave == 0) {
+            if (ADD && c.rowok) add4 = *reinterpret_cast<const f32x4 *>(a.part0 + c.fr * (ntiles * 16) + n0);
+            if (EPI == FE_CODE && a.var_bit && c.rowok) bitsv = a.bits[c.fr];
+        }
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) bad |= is_poison4(xc[u]);
+        while (__any(bad) && !c.give_up) {                 // (rare) not published yet, or a flag ahead of its block: wait, fetch again
+            s = flow_wait<PER>(g, bufb, nb, kb0, c.give_up, code, spins);
+            flow_issue<PER>(g, s, xc);
+            bad = false;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) bad |= is_poison4(xc[u]);
+            if (++spins > g.spin_limit) {
+                c.give_up = true;
+                if (lane == 0) atomicExch(g.status, code);
+            }
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const f32x4 xv = __builtin_bit_cast(f32x4, xc[u]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma16(wv[u][e], xv[e], acc);
+        }
+        if (PRE_OUT && last) {                             // the next layer's weights travel during the last chain's reduction
+            const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
+#pragma unroll
+            for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
+        }
+        float *r = c.red_lin + (c.hopctr & 1u) * (NW * 256);
+        ++c.hopctr;
+        *reinterpret_cast<f32x4 *>(r + (wave * 64 + lane) * 4) = acc;
+        __syncthreads();
+        if (wave == 0) flow_publish<EPI, ADD, REARM_H, NW>(c, hopid, r, n0, ytile, ntiles, out, bias4, add4, mean4, std4, bitsv);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) xc[u] = xn[u];
+    }
 }
 
 // GRU cell (PyTorch gate order r, z, n; bvrnn.py:206,227): gh = W_hh h, gi = W_ih [phi_x_gen ; phi_z]; in decode the
@@ -369,8 +480,10 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
     const FlowWg &g = c.g;
     const auto &a = *c.a;
     if (g.ntile >= hb) {
+        if (c.pre_now) {
 #pragma unroll
-        for (int u = 0; u < PERN; ++u) wn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < PERN; ++u) wn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         return;
     }
     const int lane = g.lane, wave = g.wave;
@@ -433,12 +546,12 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         // this workgroup's own block of h(t): written by itself a frame ago (or the initial state)
         hprev = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, hbuf + c.par * a.slot_bytes + ytile, 0, AUX_SC1));
     }
-    {   // the first layer of the next frame (after the last frame a harmless extra request: no value is carried across)
+    if (c.pre_now) {   // the first layer of the next frame (after the last frame a harmless extra request: no value is carried across)
         const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
     }
-    float *red_gru = c.red_gru;
+    float *red_gru = c.red_gru + (c.gructr & 1u) * (NW * 6 * 256);      // (two slots only when chains are interleaved: MULTI)
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         *reinterpret_cast<f32x4 *>(red_gru + ((wave * 6 + q) * 64 + lane) * 4) = gi[q];
@@ -471,7 +584,8 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         __builtin_amdgcn_raw_buffer_store_b128(publishable(hn, c.rowok), g.rs, hbuf + (c.par ^ 1u) * a.slot_bytes + ytile, 0, AUX_SC1);
         flow_stamp(c, hopid, 1);
     }
-    // red_gru is single-buffered: its next writers are a whole step (and many barriers) away
+    // one chain: red_gru is single-buffered, its next writers are a whole step (and many barriers) away; interleaved chains
+    // (MULTI) alternate between two slots, so the next writers of this slot are two barriers away
 }
 
 }  // namespace
@@ -481,9 +595,25 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
 #ifndef BVC_FLOW_WAVES_PER_SIMD
 #define BVC_FLOW_WAVES_PER_SIMD 2
 #endif
-template <int PERH, bool ENCODE, bool FILL, int NW = 8>
+// MULTI: one layer of the static program, chain by chain
+#define FLOW_EACH_CHAIN(...)                                                                                            \
+    for (int ci_ = 0; ci_ < nch; ++ci_) {                                                                               \
+        c.g.mtile = mt0 + ci_;                                                                                          \
+        c.row = c.g.mtile * 16 + (c.g.lane & 15);                                                                       \
+        c.rowok = c.row < a.B;                                                                                          \
+        c.fr = (long long)c.row * T + t;                                                                                \
+        c.pre_now = ci_ == nch - 1;                                                                                     \
+        __VA_ARGS__;                                                                                                    \
+    }
+
+// MULTI: a workgroup owns its feature tile for MG utterance groups ("chains": utterances never interact) and works through a
+// layer chain by chain with the same weight registers; by the time it returns to a chain for the next layer, that chain's
+// inputs - produced by the other workgroups in the same order - have long arrived, so the hand-off latency of one chain lies
+// under the products of the others.  Batches of more than 16 * (CUs / feature tiles) utterances (64 at h_dim 1024) run this way.
+template <int PERH, bool ENCODE, bool FILL, int NW = 8, bool MULTI = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) void bvrnn_flow_kernel(const FlowArgs *a0) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][8][256] layer partials | [8][6][256] GRU partials
+    static_assert(!(MULTI && FILL), "the filler quanta are per chain: not built for interleaved chains");
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][8][256] layer partials | [1 or 2][8][6][256] GRU partials
     const int tid = threadIdx.x;
     FlowCtx c;
     FlowArgsC ap = (FlowArgsC)(unsigned long long)a0;      // device-resident copy of the arguments (flow_set_args_kernel)
@@ -494,8 +624,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     c.g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
     const int MT = ap->MT;
-    c.g.ntile = (slot / MT) * 8 + xcd;                    // the utterance groups of a feature tile share an XCD (weights cross the fabric once)
-    c.g.mtile = slot % MT;
+    const int MG = MULTI ? ap->MG : 1;                     // chains per workgroup
+    const int MTG = MULTI ? (MT + MG - 1) / MG : MT;       // workgroups per feature tile
+    c.g.ntile = (slot / MTG) * 8 + xcd;                   // the utterance groups of a feature tile share an XCD (weights cross the fabric once)
+    const int mt0 = (slot % MTG) * MG;
+    const int nch = MULTI ? (MT - mt0 < MG ? MT - mt0 : MG) : 1;
+    c.g.mtile = mt0;
     if (c.g.ntile >= ap->NTG) return;                      // grid is rounded up to a multiple of 8 feature tiles
     c.g.rs = __builtin_amdgcn_make_buffer_rsrc(ap->flow, 0, (int)(FB_COUNT * 2u * ap->slot_bytes), 0x00020000);
     c.g.spin_limit = ap->spin_limit;
@@ -504,6 +638,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     c.row = c.g.mtile * 16 + (c.g.lane & 15);
     c.rowok = c.row < ap->B;
     c.give_up = false;
+    c.pre_now = true;
+    c.gructr = 0;
     c.probe = ap->probe != nullptr && bid == 0 && tid == 0;
     c.hopctr = 0;
     const int hb = ap->hb, zb = ap->zb, xb = ap->xb;
@@ -535,34 +671,61 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
         // h half of dec.0, the three gates of W_ih[:, H:] phi_z.  The GRU layer then only has phi_x(d_t)'s third left.
         constexpr int G0 = FILL ? 0 : -2, G1 = FILL ? 1 : -2, G2 = FILL ? 2 : -2, GP = FILL ? -1 : -2;
         const FlowFill f_hh = {a.w_hh, hb, hb, hsrc}, f_d0 = {a.dec0h.w, a.dec0h.wnb, hb, hsrc}, f_iz = {a.w_ihz, 2 * hb, hb, zsrc};
-        if (ENCODE) {
-            //         PER   epilogue  two    add    pre_in pre_out       rearm  filler
-            flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb, zero4, f_hh, &c.fgh[0]);
-            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, true, G1, NW>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa, zero4, f_hh, &c.fgh[1]);
-            flow_layer<PERH, FE_CODE, false, false, false, false, PERH, false, G2, NW>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb, zero4, f_hh, &c.fgh[2]);
-            flow_layer<1, FE_ELU, false, false, false, true, PERH, false, GP, NW>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, zero4, f_d0, &c.fd0);
-            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb);
-            if (FILL) {
-                FlowLin d0 = L(a.dec0z);                   // dec.0: only the phi_z half is left; the bias travels with dec0h
-                d0.bias = a.dec0h.bias;
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, d0, wa);
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G0, NW>(c, 7, d0, FB_Q3, d0, 0, hb, hb, FB_D1, wa, L(a.dec1), wb, c.fd0, f_iz, &c.fgi[0]);
+        if constexpr (!MULTI) {
+            if (ENCODE) {
+                //         PER   epilogue  two    add    pre_in pre_out       rearm  filler
+                flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb, zero4, f_hh, &c.fgh[0]);
+                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, true, G1, NW>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa, zero4, f_hh, &c.fgh[1]);
+                flow_layer<PERH, FE_CODE, false, false, false, false, PERH, false, G2, NW>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb, zero4, f_hh, &c.fgh[2]);
+                flow_layer<1, FE_ELU, false, false, false, true, PERH, false, GP, NW>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, zero4, f_d0, &c.fd0);
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb);
+                if (FILL) {
+                    FlowLin d0 = L(a.dec0z);                   // dec.0: only the phi_z half is left; the bias travels with dec0h
+                    d0.bias = a.dec0h.bias;
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, d0, wa);
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G0, NW>(c, 7, d0, FB_Q3, d0, 0, hb, hb, FB_D1, wa, L(a.dec1), wb, c.fd0, f_iz, &c.fgi[0]);
+                } else {
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa);
+                    flow_layer<PERH, FE_ELU, true, false, true, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb);
+                }
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_iz, &c.fgi[1]);
+                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_iz, &c.fgi[2]);
             } else {
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa);
-                flow_layer<PERH, FE_ELU, true, false, true, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb);
+                flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, zero4, f_hh, &c.fgh[0]);
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, true, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_hh, &c.fgh[1]);
+                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_hh, &c.fgh[2]);
             }
-            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_iz, &c.fgi[1]);
-            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_iz, &c.fgi[2]);
+            flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb);
+            flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa);
+            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb);
+            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, -2, NW>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa);
+            flow_gru<PERH, ENCODE, PERH, FILL, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa);
         } else {
-            flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, zero4, f_hh, &c.fgh[0]);
-            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, true, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_hh, &c.fgh[1]);
-            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_hh, &c.fgh[2]);
+            // the same program on interleaved chains (no filler quanta): wide single-segment layers pipeline their chains
+            // (flow_layer_chains), the two narrow-input layers, the two-segment dec.0 of encode and the GRU go chain by chain
+            constexpr bool E = ENCODE;
+            if (E) {
+                flow_layer_chains<PERH, FE_ELU, true, true, true, PERH, false, NW>(c, 1, L(a.enc0h), FB_H, hb, hb, FB_E1, wa, L(a.enc1), wb, mt0, nch, T);
+                flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, true, NW>(c, 2, L(a.enc1), FB_E1, hb, hb, FB_E2, wb, L(a.enc1), wa, mt0, nch, T);
+                flow_layer_chains<PERH, FE_CODE, false, false, false, PERH, false, NW>(c, 3, L(a.enc2), FB_E2, hb, zb, FB_ZC, wa, L(a.enc2), wb, mt0, nch, T);
+                FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa));
+                flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 5, L(a.pz1), FB_Q1, hb, hb, FB_Q2, wa, L(a.pz2), wb, mt0, nch, T);
+                flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 6, L(a.pz2), FB_Q2, hb, hb, FB_Q3, wb, L(a.pz2), wa, mt0, nch, T);
+                // two segments share the weight registers: the first segment's weights are fetched per chain
+                FLOW_EACH_CHAIN(flow_layer<PERH, FE_ELU, true, false, false, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb));
+                flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 8, L(a.dec1), FB_D1, hb, hb, FB_D2, wb, L(a.dec2), wa, mt0, nch, T);
+                flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.dec2), wb, mt0, nch, T);
+            } else {
+                flow_layer_chains<PERH, FE_ELU, true, true, true, PERH, false, NW>(c, 7, L(a.dec0h), FB_H, hb, hb, FB_D1, wa, L(a.dec1), wb, mt0, nch, T);
+                flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, true, NW>(c, 8, L(a.dec1), FB_D1, hb, hb, FB_D2, wb, L(a.dec2), wa, mt0, nch, T);
+                flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.dec2), wb, mt0, nch, T);
+            }
+            flow_layer_chains<PERH, FE_MEL, false, false, false, PERH, false, NW>(c, 10, L(a.dec3), FB_D3, hb, xb, FB_DN, wa, L(a.dec3), wb, mt0, nch, T);
+            FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa));
+            flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 12, L(a.px1), FB_G1, hb, hb, FB_G2, wa, L(a.px2), wb, mt0, nch, T);
+            flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 13, L(a.px2), FB_G2, hb, hb, FB_G3, wb, L(a.px2), wa, mt0, nch, T);
+            FLOW_EACH_CHAIN(flow_gru<PERH, ENCODE, PERH, false, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa); ++c.gructr);
         }
-        flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb);
-        flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa);
-        flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb);
-        flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, -2, NW>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa);
-        flow_gru<PERH, ENCODE, PERH, FILL, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa);
     }
 }
 
@@ -580,6 +743,7 @@ int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s) {
 
 constexpr size_t flow_lds(int nw) { return (size_t)(2 * nw * 256 + nw * 6 * 256) * sizeof(float); }      // 64 KiB with 8 waves
 constexpr size_t FLOW_LDS = flow_lds(8);
+constexpr size_t FLOW_LDS_MULTI = FLOW_LDS + (size_t)8 * 6 * 256 * sizeof(float);      // a second slot of GRU partials
 
 template <int PERH, bool ENC>
 static int flow_attr() {
@@ -590,6 +754,8 @@ static int flow_attr() {
 
 int flow_kernels_init() {
     int rc;
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<8, true, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_MULTI));
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<8, false, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_MULTI));
 
     if ((rc = flow_attr<1, true>()) || (rc = flow_attr<1, false>()) || (rc = flow_attr<2, true>()) || (rc = flow_attr<2, false>()) ||
         (rc = flow_attr<4, true>()) || (rc = flow_attr<4, false>()) || (rc = flow_attr<8, true>()) || (rc = flow_attr<8, false>())) return rc;
@@ -630,6 +796,14 @@ int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, bool
     static_assert(sizeof(FlowArgs) % 4 == 0, "FlowArgs is copied in dwords");
     hipLaunchKernelGGL(flow_set_args_kernel, dim3(1), dim3(256), 0, s, d_args, a);
     const FlowArgs *d_a = d_args;
+    if (a.MG > 1) {                                        // interleaved chains: more utterance groups than workgroup slots per feature tile
+        if (perh != 8) { set_error("launch_flow: interleaved chains are built for h_dim 1024 only"); return BVC_EINVAL; }
+        const int grid_m = ((a.NTG + 7) / 8) * 8 * ((a.MT + a.MG - 1) / a.MG);
+        if (encode) hipLaunchKernelGGL((bvrnn_flow_kernel<8, true, false, 8, true>), dim3(grid_m), dim3(512), FLOW_LDS_MULTI, s, d_a);
+        else        hipLaunchKernelGGL((bvrnn_flow_kernel<8, false, false, 8, true>), dim3(grid_m), dim3(512), FLOW_LDS_MULTI, s, d_a);
+        BVC_HIP_TRY(hipGetLastError());
+        return BVC_OK;
+    }
     const int grid = ((a.NTG + 7) / 8) * 8 * a.MT;
 
     switch (perh) {

@@ -83,3 +83,36 @@ def test_recurrence_schedule_can_be_switched_at_run_time():
         assert st["max_first_divergence_margin"] < 1e-5, st
     assert torch.equal(model.encode(x, 3000), codes_p)       # and back
     model.check_status()
+
+
+@pytest.mark.parametrize("B,frames", [(80, 9), (130, 5), (256, 3)])
+def test_large_batch_on_interleaved_chains_equals_layer_schedule(B, frames):
+    """More than 64 utterances exceed one workgroup per (utterance group, feature tile): the persistent kernel then
+    works through several utterance groups ("chains") per workgroup (k_flow.hip, MULTI).  Same arithmetic per output as
+    the launch-per-layer schedule: identical codes and mel, including a last, partly filled utterance group and a
+    workgroup with fewer chains than the others; and against the oracle on a few utterances."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    from oracle import codec as ocodec
+    model, conf, sd1, sd2 = make_model(True, 1024)
+    L = 256 * frames + 17
+    x = synth.synthetic_speech(B, L, seed=B, kind="speech").to(DEV)
+    try:
+        model.set_recurrence("persistent")
+        codes = model.encode(x, 3000)
+        h0 = torch.zeros(1, B, 1024, device=DEV)
+        mel, hT = model.bvrnn.decode(codes, h0)
+        torch.cuda.synchronize(DEV)
+        model.check_status()
+        model.set_recurrence("layers")
+        codes_l = model.encode(x, 3000)
+        mel_l, hT_l = model.bvrnn.decode(codes, h0)
+    finally:
+        model.set_recurrence("persistent")
+    assert torch.equal(codes, codes_l)
+    assert (mel - mel_l).abs().max().item() < 1e-5 and (hT - hT_l).abs().max().item() < 5e-6
+    oc = ocodec.OracleCodec(conf, sd1, sd2)
+    pick = [0, 63, 64, B - 1]                              # first / last utterance of groups that sit in different chains
+    r = oc.encode(x[pick].cpu(), 3000, full=True)
+    mism = codes[pick].cpu() != r["codes"]
+    assert not bool((mism & ((r["prob"] - 0.5).abs() > 1e-5)).any())

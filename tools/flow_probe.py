@@ -1,5 +1,5 @@
 """Per-layer time of the persistent recurrence as workgroup 0 sees it (entry of the layer -> its output published).
-    python tools/flow_probe.py [seconds]"""
+    python tools/flow_probe.py [seconds [batch]]"""
 import ctypes
 import os
 import sys
@@ -17,7 +17,8 @@ d = tempfile.mkdtemp()
 p1, p2 = synth.write_checkpoints(conf, d, seed=1234)
 model = BVRNNCodecModel(config.DEFAULT_CONFIG, p1, p2).to("cuda:0")
 L = int(22050 * secs)
-x = synth.synthetic_speech(64, L, seed=0, kind="noise").cuda()
+BATCH = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+x = synth.synthetic_speech(BATCH, L, seed=0, kind="noise").cuda()
 lib = _abi.load()
 for _ in range(2):
     codes = model.encode(x, 3000)
