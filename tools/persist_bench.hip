@@ -96,7 +96,10 @@ __global__ __launch_bounds__(NW * 64) void layer_ref(const float *__restrict__ x
 }
 
 // ---------------------------------------------------------------- (b) persistent, poisoned-buffer dataflow
-template <int NW, bool PREFETCH_W, int POLL, bool DIAG>
+// XMODE: how the operand blocks are fetched once their flags are up.  0: sc1 loads (device scope per access).  1: an
+// agent-scope acquire (buffer_inv sc1) after the flag poll, then ordinary loads.  2: ordinary loads with no invalidate
+// (timing reference only: may read stale lines).
+template <int NW, bool PREFETCH_W, int POLL, bool DIAG, int XMODE = 0>
 __global__ __launch_bounds__(NW * 64) void persist(Args a) {
     __shared__ __attribute__((aligned(16))) float red[2][NW * 256];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -148,8 +151,9 @@ __global__ __launch_bounds__(NW * 64) void persist(Args a) {
             } while (bad && !give_up);
         }
         u32x4 xr[PER];
+        if (XMODE == 1) asm volatile("buffer_inv sc1" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < PER; ++u) xr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xbase + u * 1024, 0, AUX_SC1));
+        for (int u = 0; u < PER; ++u) xr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xbase + u * 1024, 0, XMODE == 0 ? AUX_SC1 : 0));
         unsigned pending = 0;
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -592,6 +596,9 @@ int main(int argc, char **argv) {
     run_persist("persistent + prefetch, poll all blocks", persist<8, true, 1, false>, false);
     run_persist("persistent + prefetch, flag poll then fetch", persist<8, true, 2, false>, false);
     run_persist("  (diag build) flag poll then fetch", persist<8, true, 2, true>, true);
+    run_persist("flag poll, buffer_inv sc1, plain fetch", persist<8, true, 2, false, 1>, false);
+    run_persist("  (diag build) inv + plain fetch", persist<8, true, 2, true, 1>, true);
+    run_persist("flag poll, plain fetch, NO invalidate (timing)", persist<8, true, 2, false, 2>, false);
     run_persist("  (diag build) poll one", persist<8, true, 0, true>, true);
     run_persist("  (diag build) poll all", persist<8, true, 1, true>, true);
     }
