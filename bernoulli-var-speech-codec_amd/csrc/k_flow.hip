@@ -31,6 +31,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifndef BVC_GRU_ROUNDS_FILL
+#define BVC_GRU_ROUNDS_FILL 4      // rounds in which the GRU layer's remaining weights (phi_x third) pass through the registers
+#endif
 constexpr int AUX_SC1 = 16;
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -503,7 +506,7 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
     // requested at once and multiplied while phi_x(d_t), the input produced last, is still on its way
     // The weights stream through two register sets: the request for round i+1 is issued before round i is multiplied.
     if (!(PER == 1 && wave >= hb)) {                       // (wave-uniform) a wave without a k-block of its own contributes zeros
-        constexpr int HALF = PER >= 4 ? PER / 4 : 1;       // k-blocks per round
+        constexpr int HALF = FILL ? (PER >= BVC_GRU_ROUNDS_FILL ? PER / BVC_GRU_ROUNDS_FILL : 1) : (PER >= 4 ? PER / 4 : 1);       // k-blocks per round
         constexpr int RPS = PER / HALF;                    // rounds per segment
         constexpr int NSEG = FILL ? 1 : (ENCODE ? 3 : 2);  // FILL: the h and phi_z products were accumulated earlier in the frame
         constexpr int NR = NSEG * RPS;

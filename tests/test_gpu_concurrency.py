@@ -85,7 +85,7 @@ def test_recurrence_schedule_can_be_switched_at_run_time():
     model.check_status()
 
 
-@pytest.mark.parametrize("B,frames", [(80, 9), (130, 5), (256, 3)])
+@pytest.mark.parametrize("B,frames", [(80, 9), (130, 5), (256, 3), (512, 2)])
 def test_large_batch_on_interleaved_chains_equals_layer_schedule(B, frames):
     """More than 64 utterances exceed one workgroup per (utterance group, feature tile): the persistent kernel then
     works through several utterance groups ("chains") per workgroup (k_flow.hip, MULTI).  Same arithmetic per output as
