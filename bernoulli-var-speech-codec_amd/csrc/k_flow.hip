@@ -31,6 +31,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifndef BVC_FILL_ORDER
+#define BVC_FILL_ORDER 0
+#endif
 #ifndef BVC_GRU_ROUNDS_FILL
 #define BVC_GRU_ROUNDS_FILL 4      // rounds in which the GRU layer's remaining weights (phi_x third) pass through the registers
 #endif
@@ -367,12 +370,17 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
     }
-    if (FGATE != -2) fill_issue<PERN, FGATE>(g, fill, fw, fx);
+    // BVC_FILL_ORDER: 0 every wave requests its filler operands before the barrier; 1 the publishing wave requests its own behind
+    // its store (a CU's address path takes 64 B per clock: 16 KiB of requests in front of the store everybody waits for); 2 all
+    // waves behind the store.  Measured 56.4 / 56.8 / 59.1 ms per step: behind the store the layer spans get 1 us shorter
+    // (tools/flow_probe.py), but the filler's own fetch is then exposed behind the layer instead of travelling under its reduction.
+    if (FGATE != -2 && (BVC_FILL_ORDER == 0 || (BVC_FILL_ORDER == 1 && wave != 0))) fill_issue<PERN, FGATE>(g, fill, fw, fx);
     float *r = c.red_lin + (c.hopctr & 1u) * (NW * 256);
     ++c.hopctr;
     *reinterpret_cast<f32x4 *>(r + (wave * 64 + lane) * 4) = acc;
     __syncthreads();
     if (wave == 0) flow_publish<EPI, ADD, REARM_H, NW>(c, hopid, r, n0, ytile, ntiles, out, bias4, add4, mean4, std4, bitsv);
+    if (FGATE != -2 && (BVC_FILL_ORDER == 2 || (BVC_FILL_ORDER == 1 && wave == 0))) fill_issue<PERN, FGATE>(g, fill, fw, fx);
     if (FGATE != -2) fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc);
 }
 
