@@ -374,6 +374,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
     // its store (a CU's address path takes 64 B per clock: 16 KiB of requests in front of the store everybody waits for); 2 all
     // waves behind the store.  Measured 56.4 / 56.8 / 59.1 ms per step: behind the store the layer spans get 1 us shorter
     // (tools/flow_probe.py), but the filler's own fetch is then exposed behind the layer instead of travelling under its reduction.
+    // (Requested earlier still - right behind the layer's own operand requests - the layers get slower: 53.9 vs 49.3 us per frame.)
     if (FGATE != -2 && (BVC_FILL_ORDER == 0 || (BVC_FILL_ORDER == 1 && wave != 0))) fill_issue<PERN, FGATE>(g, fill, fw, fx);
     float *r = c.red_lin + (c.hopctr & 1u) * (NW * 256);
     ++c.hopctr;
