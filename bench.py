@@ -281,7 +281,7 @@ def main():
 
     T = codes.shape[1]
     names = {"codec": "full encode -> BigVGAN decode", "encode": "encode only (STFT/mel + BVRNN.encode, no vocoder)"}
-    cfgname = ("configs[1]" if (full and a.seconds == 5.0) else "configs[2]" if a.seconds == 5.0 else
+    cfgname = ("custom" if B != BATCH else "configs[1]" if (full and a.seconds == 5.0) else "configs[2]" if a.seconds == 5.0 else
                "configs[3] shard (one GPU's 64 of 512 x 10 s)" if (full and a.seconds == 10.0) else "custom")
     out = {
         "metric": "audio-seconds coded per wall-second (encode+decode), 22.05 kHz @ 3 kbit/s" if (full and a.bitrate == BITRATE) else
