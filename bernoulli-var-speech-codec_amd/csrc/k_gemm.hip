@@ -485,13 +485,22 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
         wok[i] = col < N;
         wp[i] = w + (long long)(wok[i] ? col : (N - 1)) * ldw + g * 4;
     }
+    // The fragments of k-block kb+1 are requested before block kb is multiplied (unconditionally: past the end the last block
+    // is read again), so that only the first request's latency is exposed - these are the K = 64 / 80 first layers, five blocks.
     const int nblk = K >> 4;
+    f32x4 xv[4], wv[4], xn[4], wn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xv[i] = *reinterpret_cast<const f32x4 *>(xp[i]);
+        wv[i] = *reinterpret_cast<const f32x4 *>(wp[i]);
+    }
+#pragma unroll 1
     for (int kb = 0; kb < nblk; ++kb) {
-        f32x4 xv[4], wv[4];
+        const long long nxt = (long long)(kb + 1 < nblk ? kb + 1 : nblk - 1) * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            xv[i] = *reinterpret_cast<const f32x4 *>(xp[i] + (long long)kb * 16);
-            wv[i] = *reinterpret_cast<const f32x4 *>(wp[i] + (long long)kb * 16);
+            xn[i] = *reinterpret_cast<const f32x4 *>(xp[i] + nxt);
+            wn[i] = *reinterpret_cast<const f32x4 *>(wp[i] + nxt);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -500,6 +509,9 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(xv[i][e], wv[j][e], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xv[i] = xn[i]; wv[i] = wn[i]; }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
