@@ -18,6 +18,9 @@
 // bvrnn.py:44-83,163-229.
 #include <cstdlib>
 
+#include <cstdint>
+#include <type_traits>
+
 #include "bvc_internal.h"
 
 namespace bvc {
@@ -454,7 +457,10 @@ __device__ __forceinline__ long long out_index(int row, int col, int N, long lon
 
 // ------------------------------------------------------------------------------------------------
 // Batched GEMM: y[M,N] = act(x[M,K] @ w[N,K]^T + bias).  128x128 per workgroup, 64x64 per wave.
-template <int ACT>
+// ROWVEC (GO_NATURAL output, N and ldy multiples of 4): the MFMA operands are swapped (tile of y^T = w x^T), so that a lane's four
+// results are four CONSECUTIVE COLUMNS of one output row and leave as one 16-byte store (the K = 64 / 80 first layers are bound by
+// their 113 MB of output: 64 four-byte stores per lane otherwise).  Same products, same order of summation per output.
+template <int ACT, bool ROWVEC = false>
 __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restrict__ x, long long ldx,
                                                            const float *__restrict__ w, long long ldw,
                                                            const float *__restrict__ bias, int M, int N,
@@ -508,10 +514,32 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(xv[i][e], wv[j][e], acc[i][j]);
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = ROWVEC ? mfma16(wv[j][e], xv[i][e], acc[i][j]) : mfma16(xv[i][e], wv[j][e], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xv[i] = xn[i]; wv[i] = wn[i]; }
+    }
+    if (ROWVEC) {                                          // acc[i][j][e] = y[m0 + 16 i + r][n0 + 16 j + 4 g + e]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + i * 16 + r;
+            if (row >= M) continue;
+            float *yr = y + (long long)row * ldy + n0 + g * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + j * 16 + g * 4;
+                if (col >= N) continue;
+                const f32x4 b4 = bias ? *reinterpret_cast<const f32x4 *>(bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 v = acc[i][j] + b4;
+                if (ACT == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = elu1(v[e]);
+                }
+                *reinterpret_cast<f32x4 *>(yr + j * 16) = v;
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -540,7 +568,7 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
 // produce the same bits.
 // BM: rows per workgroup tile, 128 or 64 (the half-height form finishes the last, partly filled round of a launch: see
 // launch_gemm_batched); m_off: first row of this launch's tiles.
-template <int ACT, int BM>
+template <int ACT, int BM, bool ROWVEC = false>
 __global__ __launch_bounds__(256, 2) void gemm_batched_lds_kernel(const float *__restrict__ x, long long ldx,
                                                                   const float *__restrict__ w, long long ldw,
                                                                   const float *__restrict__ bias, int M, int N,
@@ -608,13 +636,33 @@ __global__ __launch_bounds__(256, 2) void gemm_batched_lds_kernel(const float *_
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(av[i][e], bv[j][e], acc[i][j]);
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = ROWVEC ? mfma16(bv[j][e], av[i][e], acc[i][j]) : mfma16(av[i][e], bv[j][e], acc[i][j]);
         }
         if (more) park((kt + 1) & 1);
         __syncthreads();
     }
 
     const int m0 = mblk + wm, n0 = nblk + wn;
+    if (ROWVEC) {           // operands swapped (tile of y^T): acc[i][j][e] = y[m0 + 16 i + r][n0 + 16 j + 4 g + e], one 16-byte granule in every
+#pragma unroll              // output layout (see gemm_batched_kernel)
+        for (int i = 0; i < MI; ++i) {
+            const int row = m0 + i * 16 + r;
+            if (row >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = n0 + j * 16 + g * 4;
+                const f32x4 b4 = bias ? *reinterpret_cast<const f32x4 *>(bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 v = acc[i][j] + b4;
+                if (ACT == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = elu1(v[e]);
+                }
+                *reinterpret_cast<f32x4 *>(y + out_index(row, col, N, ldy, frames_T, mt16, out_mode)) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + j * 16 + r;
@@ -656,12 +704,20 @@ int launch_gemm_batched(const float *x, long long ldx, const float *w, long long
         const size_t lds = (size_t)2 * 2 * 128 * 36 * sizeof(float);
         static bool attr = false;
         if (!attr) {
-            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<0, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<1, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<0, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_batched_lds_kernel<1, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const void *ks[] = {(const void *)gemm_batched_lds_kernel<0, 128, false>, (const void *)gemm_batched_lds_kernel<1, 128, false>,
+                                (const void *)gemm_batched_lds_kernel<0, 64, false>,  (const void *)gemm_batched_lds_kernel<1, 64, false>,
+                                (const void *)gemm_batched_lds_kernel<0, 128, true>,  (const void *)gemm_batched_lds_kernel<1, 128, true>,
+                                (const void *)gemm_batched_lds_kernel<0, 64, true>,   (const void *)gemm_batched_lds_kernel<1, 64, true>};
+            for (const void *k : ks) BVC_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr = true;
         }
+        // 16-byte epilogue stores (operands swapped, see gemm_batched_kernel) whenever the output granules are aligned
+        const bool rv = N % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+        auto launch = [&](auto act_c, auto bm_c, dim3 grid_, int m_off_) {
+            constexpr int A_ = decltype(act_c)::value, BM_ = decltype(bm_c)::value;
+            if (rv) hipLaunchKernelGGL((gemm_batched_lds_kernel<A_, BM_, true>), grid_, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, m_off_);
+            else    hipLaunchKernelGGL((gemm_batched_lds_kernel<A_, BM_, false>), grid_, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, m_off_);
+        };
         // Tail: 2 workgroups fit a CU, so the chip takes 512 tiles per round; a grid that ends with a partly filled round
         // (configs[1]: 215 x 8 = 1,720 tiles = 3.36 rounds) pays a whole round for it.  The rows of that last round are
         // computed with half-height tiles instead (a second launch; the same k order per accumulator, so the same bits).
@@ -673,19 +729,24 @@ int launch_gemm_batched(const float *x, long long ldx, const float *w, long long
             full_blk = (rows_blk / per_round) * per_round;
         if (full_blk > 0) {
             dim3 g1(ncol, full_blk);
-            if (act == 1) hipLaunchKernelGGL((gemm_batched_lds_kernel<1, 128>), g1, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, 0);
-            else          hipLaunchKernelGGL((gemm_batched_lds_kernel<0, 128>), g1, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, 0);
+            if (act == 1) launch(std::integral_constant<int, 1>(), std::integral_constant<int, 128>(), g1, 0);
+            else          launch(std::integral_constant<int, 0>(), std::integral_constant<int, 128>(), g1, 0);
         }
         if (full_blk < rows_blk) {
             const int m_off = full_blk * 128;
             dim3 g2(ncol, (M - m_off + 63) / 64);
-            if (act == 1) hipLaunchKernelGGL((gemm_batched_lds_kernel<1, 64>), g2, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, m_off);
-            else          hipLaunchKernelGGL((gemm_batched_lds_kernel<0, 64>), g2, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, m_off);
+            if (act == 1) launch(std::integral_constant<int, 1>(), std::integral_constant<int, 64>(), g2, m_off);
+            else          launch(std::integral_constant<int, 0>(), std::integral_constant<int, 64>(), g2, m_off);
         }
         BVC_HIP_TRY(hipGetLastError());
         return BVC_OK;
     }
-    if (act == 1)
+    const bool rowvec = out_mode == GO_NATURAL && N % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                        (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+    if (rowvec) {
+        if (act == 1) hipLaunchKernelGGL((gemm_batched_kernel<1, true>), grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode);
+        else          hipLaunchKernelGGL((gemm_batched_kernel<0, true>), grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode);
+    } else if (act == 1)
         hipLaunchKernelGGL(gemm_batched_kernel<1>, grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode);
     else
         hipLaunchKernelGGL(gemm_batched_kernel<0>, grid, dim3(256), 0, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode);
