@@ -169,31 +169,32 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int n = 0; n < NTW; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bw[u][n], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[u][n], av[i], acc[i][n], 0, 0, 0);      // tile of out^T (below)
             }
         }
     }
 
-    // ---- epilogue: D[row = g*4+e][col = r]
+    // ---- epilogue.  The operands are swapped (weights as A, activations as B), so acc[i][n][e] = out[row mbase+16i+r][col 16(ntile0+n)+4g+e]:
+    // a lane's four results are four consecutive channels of one output row - one 16-byte store (cout is a multiple of 4).
     const long long ob = (long long)b * a.out_bs;
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-        const int col = (ntile0 + n) * 16 + r;
-        if (col >= a.cout) continue;
-        const float bias = a.bias[col];
+    for (int i = 0; i < MT; ++i) {
+        const long long t = t0 + mbase + i * 16 + r;
+        if (t >= a.Lout) continue;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int n = 0; n < NTW; ++n) {
+            const int col = (ntile0 + n) * 16 + g * 4;
+            if (col >= a.cout) continue;
+            const long long o = ob + t * a.cout + col;
+            f32x4 v = acc[i][n] + *reinterpret_cast<const f32x4 *>(a.bias + col);
+            if (a.epi >= CE_RES) v = v + *reinterpret_cast<const f32x4 *>(a.res + o);        // x = xt + x      (models.py:119)
+            if (a.epi >= CE_RES_ACC) v = *reinterpret_cast<const f32x4 *>(a.acc + o) + v;    // xs += resblock  (models.py:224)
+            if (a.epi == CE_RES_ACC_DIV) {                                                   // xs / num_kernels (models.py:225)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const long long t = t0 + mbase + i * 16 + g * 4 + e;
-                if (t >= a.Lout) continue;
-                const long long o = ob + t * a.cout + col;
-                float v = acc[i][n][e] + bias;
-                if (a.epi >= CE_RES) v = v + a.res[o];               // x = xt + x      (models.py:119)
-                if (a.epi >= CE_RES_ACC) v = a.acc[o] + v;           // xs += resblock  (models.py:224)
-                if (a.epi == CE_RES_ACC_DIV) v = v / a.divisor;      // xs / num_kernels (models.py:225)
-                a.out[o] = v;
+                for (int e = 0; e < 4; ++e) v[e] = v[e] / a.divisor;
             }
+            *reinterpret_cast<f32x4 *>(a.out + o) = v;
+        }
     }
 }
 
@@ -877,6 +878,7 @@ int conv_kernels_init() {
 int launch_conv_mfma(const ConvLayer &c, const float *in, long long Lin, float *out, long long Lout, int B,
                      int epi, const float *res, const float *acc, float divisor, hipStream_t s, const ConvWindow *win) {
     if (B <= 0 || Lout <= 0) return BVC_OK;
+    if (c.cout % 4) { set_error("conv_mfma: %d output columns (the epilogue stores 16-byte granules)", c.cout); return BVC_EINVAL; }
     ConvArgs a;
     a.in = in; a.Lin = Lin; a.out = out; a.Lout = Lout; a.res = res; a.acc = acc;
     a.in_bs = win ? win->in_bs : Lin * c.cin;
