@@ -555,8 +555,11 @@ __global__ __launch_bounds__(256, OCC) void amp_pair8_kernel(AmpArgs a) {
         }
     const f32x4 aa1 = *reinterpret_cast<const f32x4 *>(a.a1 + (tid & 1) * 4);      // phase 1: item idx has channels (idx & 1) * 4 ..; idx & 1 == tid & 1
     const f32x4 bb1 = *reinterpret_cast<const f32x4 *>(a.ib1 + (tid & 1) * 4);
-    const int p = r >> 3, co = r & 7;
-    const float bias1 = a.b1[co], aa2 = a.a2[co], bb2 = a.ib2[co], bias2 = a.b2[co];
+    // The MFMA operands are swapped (weights as A, activations as B): acc[i][e] = out[pair mbase + 16 i + r][column 4 g + e], column =
+    // p * 8 + co - a lane's four results are four consecutive channels of ONE row, so the epilogues work on 16-byte granules
+    const int p = g >> 1, co0 = (g & 1) * 4;
+    const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.b1 + co0), aa2 = *reinterpret_cast<const f32x4 *>(a.a2 + co0);
+    const f32x4 bb2 = *reinterpret_cast<const f32x4 *>(a.ib2 + co0), bias2 = *reinterpret_cast<const f32x4 *>(a.b2 + co0);
 
     auto tile_origin = [&](unsigned bid, int &b, long long &t0) {
         b = (int)(bid / (unsigned)a.tiles_per_batch);
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(256, OCC) void amp_pair8_kernel(AmpArgs a) {
 #pragma unroll
                 for (int i = 0; i < MT2; ++i) av[i] = arow[(pos + i * 16) * S + q * 4];
 #pragma unroll
-                for (int i = 0; i < MT2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wreg[k][q], acc[i], 0, 0, 0);
+                for (int i = 0; i < MT2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[k][q], av[i], acc[i], 0, 0, 0);      // tile of out^T: see the epilogues
             }
         }
     };
@@ -635,19 +638,16 @@ __global__ __launch_bounds__(256, OCC) void amp_pair8_kernel(AmpArgs a) {
             const int zrow = zr64 <= 0 ? 0 : (zr64 > TR ? TR : (int)zr64);      // (the reference pads AFTER the activation)
 #pragma unroll
             for (int i = 0; i < MT2; ++i) {
-                // pairs m .. m+3 of this lane: R(m) by one division, then stepped (R(m+1) = R(m) + 1, + D more when a block ends)
-                const int m0 = mbase + i * 16 + g * 4;
-                int rem = m0 % D, rowr = pair_row<D>(m0) + p * D;
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const f32x2 s2 = snakebeta2((f32x2){acc[i][e] + bias1, acc[i][e + 1] + bias1}, splat2(aa2), splat2(bb2));
-                    const int row0 = rowr;
-                    rowr += rem == D - 1 ? D + 1 : 1; rem = rem == D - 1 ? 0 : rem + 1;
-                    const int row1 = rowr;
-                    rowr += rem == D - 1 ? D + 1 : 1; rem = rem == D - 1 ? 0 : rem + 1;
-                    const float v0 = row0 >= zrow ? s2[0] : 0.0f, v1 = row1 >= zrow ? s2[1] : 0.0f;
-                    if (NPE == NP || m0 + e < NPE) lds[row_pos<1>(row0, H2) * S + co] = v0;
-                    if (NPE == NP || m0 + e + 1 < NPE) lds[row_pos<1>(row1, H2) * S + co] = v1;
+                const int m = mbase + i * 16 + r;          // this lane's pair; its row of column block p
+                const int row = pair_row<D>(m) + p * D;
+                const f32x4 u4 = acc[i] + bias1;
+                const f32x2 s01 = snakebeta2((f32x2){u4[0], u4[1]}, (f32x2){aa2[0], aa2[1]}, (f32x2){bb2[0], bb2[1]});
+                const f32x2 s23 = snakebeta2((f32x2){u4[2], u4[3]}, (f32x2){aa2[2], aa2[3]}, (f32x2){bb2[2], bb2[3]});
+                const bool keep = row >= zrow;
+                if (NPE == NP || m < NPE) {
+                    float2 *dst = reinterpret_cast<float2 *>(lds + row_pos<1>(row, H2) * S + co0);
+                    dst[0] = keep ? make_float2(s01[0], s01[1]) : make_float2(0.f, 0.f);
+                    dst[1] = keep ? make_float2(s23[0], s23[1]) : make_float2(0.f, 0.f);
                 }
             }
             // rows conv1 did not produce ([TR1, TR + KS]): read only by discarded outputs, but keep them defined
@@ -674,9 +674,12 @@ __global__ __launch_bounds__(256, OCC) void amp_pair8_kernel(AmpArgs a) {
         conv(std::integral_constant<int, 1>(), H2, w2reg);
         __syncthreads();                                   // t2 is dead: the LDS now stages the output tile, row-major
 #pragma unroll
-        for (int i = 0; i < MT2; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) lds[(2 * (mbase + i * 16 + g * 4 + e) + p) * S + co] = acc[i][e] + bias2;
+        for (int i = 0; i < MT2; ++i) {
+            const f32x4 o4 = acc[i] + bias2;
+            float2 *dst = reinterpret_cast<float2 *>(lds + (2 * (mbase + i * 16 + r) + p) * S + co0);
+            dst[0] = make_float2(o4[0], o4[1]);
+            dst[1] = make_float2(o4[2], o4[3]);
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NLD3; ++i) {
