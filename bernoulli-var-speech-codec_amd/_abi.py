@@ -41,6 +41,7 @@ SIGNATURES = {
                                         ctypes.POINTER(_vp)]),
     "bvc_model_destroy": (None, [_vp]),
     "bvc_model_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _i32]),
+    "bvc_model_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(_i32)]),
     "bvc_model_status": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "bvc_num_frames": (_i64, [_vp, _i64]),
     "bvc_vocoder_length": (_i64, [_vp, _i64]),
@@ -71,6 +72,8 @@ SIGNATURES = {
     "bvc_kprobe_enable": (ctypes.c_int, [_i32]),
     "bvc_kprobe_read": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                        ctypes.POINTER(_i32)]),
+    "bvc_kprobe_read_span": (ctypes.c_int, [_i32, _i32, _i32, _i32, ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i32)]),
     "bvc_test_linear": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "bvc_test_linear_batched": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "bvc_test_snakebeta": (ctypes.c_int, [_vp, _i64, _f, _f, _vp, _vp]),

@@ -149,6 +149,7 @@ int launch_repack_rows(const float *src, float *dst, long long ld_natural, int r
 // (see k_flow.hip).  Activations live in the flow region of the workspace: FlowBuf id, frame parity ->
 // flow + (id * 2 + parity) * slot_bytes, each a fragment-packed [MT16][dim] matrix.
 constexpr unsigned FLOW_POISON = 0xFFFFDEADu;      // a NaN bit pattern no layer may publish as data
+constexpr int FLOW_STAMPS = 6;                     // stamp kinds per layer and frame (k_flow.hip: flow_stamp)
 enum FlowEpi { FE_ELU = 0, FE_CODE = 1, FE_MEL = 2, FE_GRU = 3 };
 enum FlowBuf { FB_H = 0, FB_E1, FB_E2, FB_ZC, FB_Q1, FB_Q2, FB_Q3, FB_D1, FB_D2, FB_D3, FB_DN, FB_G1, FB_G2, FB_G3, FB_COUNT };
 struct FlowLin {         // one K-segment of a layer as the persistent kernel sees it (32-/64-bit fields: scalar loads)
@@ -174,10 +175,14 @@ struct FlowArgs {
     const float *mean, *stdv;
     int var_bit;
     unsigned *status; unsigned spin_limit;
-    unsigned long long *probe;              // bench only: [2][T][nodes] s_memrealtime stamps of workgroup 0 (layer entry / exit)
+    unsigned long long *probe;              // bench only: [FLOW_STAMPS][T][nodes] s_memrealtime stamps of one wave (0 layer entry, 1 exit, 2.. diagnostics)
     int probe_nodes, probe_first;           // layers per frame, id of the first one
+    int probe_wg, probe_wave;               // which workgroup / wave stamps (BVC_PROBE_WG / BVC_PROBE_WAVE, default 0 / 0)
     int dbg_hot_w;                          // experiments only (BVC_FLOW_HOTW=1): every weight request hits the same blocks (wrong results)
     int MG;                                 // utterance groups (chains) per workgroup; 1 = one chain (B <= 16 * CUs / feature tiles)
+    unsigned *census;                       // != null: residency census only - every workgroup adds 1 to census[0] and waits (bounded by
+                                            // spin_limit) until all gridDim.x have; census[1] counts the workgroups that gave up
+    int dbg_withhold;                       // tests only: workgroup 0 returns at once
 };
 int flow_kernels_init();
 int flow_perh(int h_dim);

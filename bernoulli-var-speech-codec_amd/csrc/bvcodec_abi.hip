@@ -30,7 +30,7 @@ struct ProbeState {
     std::vector<hipEvent_t> ev;          // pairs
 };
 static ProbeState g_probe;
-static bool g_capturing = false;           // no event probes while a stream is being captured
+static thread_local bool g_capturing = false;   // no event probes while THIS thread captures a stream (captures are thread-local)
 static thread_local bool g_stream_tick = false;   // inside bvc_stream_codec_tick: launch-per-layer schedule, launched eagerly (the tick itself is the graph)
 
 // in-kernel timestamp probes for the graph-replayed recurrent kernels (wall_clock64, 100 MHz)
@@ -95,16 +95,26 @@ struct bvc_model {
     bool precomp_pz = true;     // decode: the phi_z halves of dec.0 and of the GRU input product are batched over all frames
     int mtw = 1;                // 16-row tiles per workgroup in the recurrent kernels (BVC_MTW = 1 | 2 | 4)
     // persistent recurrence (k_flow.hip): hop tables of encode / decode, resident in device memory
-    bool use_flow = true;       // BVC_RECURRENCE=layers selects the launch-per-layer schedule instead
+    // recurrence schedule: RS_PERSISTENT one launch per call (k_flow.hip), RS_LAYERS one launch per layer (hipGraph replay),
+    // RS_AUTO (default) persistent while calls come one at a time, layers while calls of several streams overlap
+    int recurrence = 2;         // BVC_RECURRENCE=persistent|layers|auto, bvc_model_set_option("recurrence")
+    bool flow_resident = false; // the residency census at creation found a full persistent grid co-resident on this device
     int flow_perh = 0;          // k-blocks per wave of an h_dim-sized segment (0: h_dim not supported by the persistent kernel)
-    unsigned *d_status = nullptr;       // sticky: set by a persistent kernel whose wait timed out
+    // sticky status word of the persistent kernels, in host-mapped pinned memory: a kernel whose wait timed out stores its
+    // code there; every compute entry point reads it WITHOUT synchronising (h_status) and reports BVC_ETIMEOUT once
+    volatile unsigned *h_status = nullptr;
+    unsigned *d_status = nullptr;       // device address of the same word
     int cu_count = 0;                   // compute units of the device: a persistent launch needs one per workgroup
+    unsigned flow_spin_limit = 4000000u;   // polls before a wait gives up (> 1 s: only a workgroup that never became resident gets there)
+    int flow_debug_withhold = 0;        // tests only: workgroup 0 of a persistent launch returns at once (its peers time out)
+    int flow_debug_nofill = 0;          // tests only: no filler quanta (the plain layer program)
 
     ~bvc_model() {
         for (auto &g : graphs) { (void)hipGraphExecDestroy(g.exec1); (void)hipGraphExecDestroy(g.execN); if (g.idle) (void)hipEventDestroy(g.idle); }
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         if (side_stream) (void)hipStreamDestroy(side_stream);
         for (auto e : cap_events) (void)hipEventDestroy(e);
+        if (h_status) (void)hipHostFree(const_cast<unsigned *>(h_status));
         for (void *p : allocs) (void)hipFree(p);
     }
 };
@@ -788,7 +798,10 @@ int run_recurrence(const bvc_model *m, const Workspace &w, void *ws_base, int B,
     const std::vector<StepNode> plan = build_step(m, w, B, kind);
     // (begin_call was given count_kernels(build_step(...)) kernels per step)
     int rc;
-    if (!m->use_graph || g_stream_tick) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    // a caller's capture takes the kernels directly (no graph of our own is built, replayed or marked idle inside it)
+    if (!m->use_graph || g_stream_tick || cs != hipStreamCaptureStatusNone) {
         int rc2;
         for (int64_t t = 0; t < T; ++t)
             if ((rc2 = launch_steps(m, plan, w, 1, s, nullptr))) return rc2;
@@ -841,20 +854,37 @@ int read_state(const Workspace &w, int B, int H, int64_t T, float *d_hT, hipStre
 
 // ---- persistent recurrence (k_flow.hip): hop tables and launch -----------------------------------------
 // Is the model laid out for the persistent kernel?  (h_dim a multiple of 128 up to 1024 or below 128; narrow z / mel layers)
+int flow_census(bvc_model *m);
+
 int build_flow(bvc_model *m) {
     const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
     m->flow_perh = flow_perh(H);
     if (Z > 128 || X > 128) m->flow_perh = 0;
     if (!m->flow_perh) return BVC_OK;
-    void *st = nullptr;
-    BVC_HIP_TRY(hipMalloc(&st, 64));
-    m->allocs.push_back(st);
-    BVC_HIP_TRY(hipMemset(st, 0, 64));
-    m->d_status = static_cast<unsigned *>(st);
+    void *st = nullptr, *dst = nullptr;
+    BVC_HIP_TRY(hipHostMalloc(&st, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(st, 0, 64);
+    m->h_status = static_cast<volatile unsigned *>(st);
+    BVC_HIP_TRY(hipHostGetDevicePointer(&dst, st, 0));
+    m->d_status = static_cast<unsigned *>(dst);
     int dev = 0;
     BVC_HIP_TRY(hipGetDevice(&dev));
     BVC_HIP_TRY(hipDeviceGetAttribute(&m->cu_count, hipDeviceAttributeMultiprocessorCount, dev));
-    return flow_kernels_init();
+    int rc = flow_kernels_init();
+    if (rc) return rc;
+    return flow_census(m);
+}
+
+// Reads the sticky status word (no synchronisation): the first call after a persistent kernel gave up reports it.
+int sticky_status(const bvc_model *m) {
+    if (!m || !m->h_status) return BVC_OK;
+    const unsigned v = *m->h_status;
+    if (!v) return BVC_OK;
+    *m->h_status = 0u;
+    set_error("a persistent recurrence kernel of an earlier call gave up waiting (frame %u, layer %u): the results of that call "
+              "are invalid.  All its workgroups must be resident together - is another process using this GPU?",
+              (v & 0x7FFFFFFFu) >> 4, (v & 15u));
+    return BVC_ETIMEOUT;
 }
 
 inline FlowLin flin(const Linear &l, size_t kb_offset = 0, bool with_bias = true) {
@@ -894,10 +924,14 @@ void flow_layers(const bvc_model *m, bool encode, FlowArgs *a) {
 // up to 64 utterances at h_dim 1024).  Anything else takes the launch-per-layer schedule.
 // Larger batches interleave MG utterance groups ("chains") per workgroup (h_dim 1024 only; k_flow.hip, MULTI).
 constexpr int FLOW_MAX_CHAINS = 8;
-inline int flow_chains(const bvc_model *m, int B) {       // 0: not usable; else utterance groups per workgroup
-    if (!m->use_flow || g_stream_tick || m->flow_perh <= 0) return 0;
+enum { RS_PERSISTENT = 0, RS_LAYERS = 1, RS_AUTO = 2 };
+inline int flow_grid_tiles(const bvc_model *m) {          // feature tiles covered by a persistent grid (rounded up to 8: one per XCD)
     const int H = m->cfg.h_dim, X = m->cfg.num_mels, Z = m->cfg.z_dim;
-    const int ntg = ((H > X ? (H > Z ? H : Z) : (X > Z ? X : Z)) / 16 + 7) / 8 * 8;
+    return ((H > X ? (H > Z ? H : Z) : (X > Z ? X : Z)) / 16 + 7) / 8 * 8;
+}
+inline int flow_chains_static(const bvc_model *m, int B) {      // 0: not usable; else utterance groups per workgroup
+    if (m->recurrence == RS_LAYERS || m->side_branch || !m->flow_resident || g_stream_tick || m->flow_perh <= 0) return 0;
+    const int ntg = flow_grid_tiles(m);
     const int mt = (B + 15) / 16;
     const int slots = m->cu_count / ntg;                   // workgroups per feature tile that fit on the device
     if (slots <= 0) return 0;
@@ -907,9 +941,6 @@ inline int flow_chains(const bvc_model *m, int B) {       // 0: not usable; else
     if (no_multi || m->flow_perh != 8 || mg > FLOW_MAX_CHAINS) return 0;
     return mg;
 }
-inline bool flow_usable(const bvc_model *m, int B) { return flow_chains(m, B) > 0; }
-
-inline float *flow_buf(const Workspace &w, int id, int parity) { return w.flow + (size_t)(id * 2 + parity) * w.flow_slot; }
 
 // The persistent kernel needs all its workgroups resident at once (they wait for each other), so launches from
 // different streams are serialised through one event: at most one is in flight per process and device.
@@ -917,14 +948,96 @@ std::mutex g_flow_mu;
 constexpr int FLOW_MAX_TICKETS = 2;
 hipEvent_t g_flow_ev[16][FLOW_MAX_TICKETS] = {};
 unsigned long long g_flow_n[16] = {};
+// RS_AUTO: the end of the last recurrence-bearing call on this device (any model of this process) and the stream it ran on.
+// A call that starts while the previous one - issued on ANOTHER stream - is still running has company: batches are in flight
+// on several streams, where the launch-per-layer chains of the streams interleave on the chip while persistent launches (each takes
+// every compute unit) would run one after the other.  The switch is sticky for AUTO_HOLD calls so that all streams change together.
+struct LastCall { hipEvent_t ev = nullptr; hipStream_t s = nullptr; bool any = false; int hold = 0; };
+LastCall g_last_call[16];
+constexpr int AUTO_HOLD = 2;
+
+// Which schedule does THIS call take?  0: launch per layer; else utterance groups per workgroup of the persistent kernel.
+// Called once per recurrence-bearing call (run_encode / run_decode); mark_call_end() follows at its end.
+int flow_chains(const bvc_model *m, int B, hipStream_t s) {
+    const int chains = flow_chains_static(m, B);
+    if (!chains) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    // a caller's capture: the persistent launch cannot be captured (its one-at-a-time ticket is a host-side wait on an event
+    // recorded outside the capture, and replays would skip it): captured calls take the launch-per-layer kernels
+    if (cs != hipStreamCaptureStatusNone) return 0;
+    if (m->recurrence != RS_AUTO) return chains;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return chains; }
+    std::lock_guard<std::mutex> lk(g_flow_mu);
+    LastCall &lc = g_last_call[dev & 15];
+    const bool company = lc.any && lc.s != s && hipEventQuery(lc.ev) == hipErrorNotReady;
+    (void)hipGetLastError();
+    if (company) lc.hold = AUTO_HOLD;
+    else if (lc.hold > 0) --lc.hold;
+    return (company || lc.hold > 0) ? 0 : chains;
+}
+
+int mark_call_end(hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return BVC_OK; }
+    int dev = 0;
+    BVC_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_flow_mu);
+    LastCall &lc = g_last_call[dev & 15];
+    if (!lc.ev) BVC_HIP_TRY(hipEventCreateWithFlags(&lc.ev, hipEventDisableTiming));
+    BVC_HIP_TRY(hipEventRecord(lc.ev, s));
+    lc.s = s; lc.any = true;
+    return BVC_OK;
+}
+
+inline float *flow_buf(const Workspace &w, int id, int parity) { return w.flow + (size_t)(id * 2 + parity) * w.flow_slot; }
+
+// One-off at model creation: can a full persistent grid (one workgroup per compute unit the device reports) be resident at
+// once?  The kernel itself is launched in census mode - same registers, same LDS - : every workgroup adds itself to a counter
+// and waits (bounded) until all have.  A CU mask, a partition mode or another tenant of the device that keeps workgroups from
+// becoming co-resident shows up here; the model then stays on the launch-per-layer schedule (flow_resident = false).
+int flow_census(bvc_model *m) {
+    m->flow_resident = false;
+    const int ntg = flow_grid_tiles(m);
+    const int slots = m->cu_count / ntg;
+    if (slots <= 0) return BVC_OK;
+    unsigned *ctr = nullptr;
+    BVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctr), 64));
+    m->allocs.push_back(ctr);
+    BVC_HIP_TRY(hipMemset(ctr, 0, 64));
+    FlowArgs *d_args = nullptr;
+    BVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_args), sizeof(FlowArgs)));
+    FlowArgs a;
+    memset(&a, 0, sizeof(a));
+    a.census = ctr;
+    a.MT = slots; a.MG = 1; a.NTG = ntg;
+    static const bool over = getenv("BVC_FLOW_CENSUS_OVERSUBSCRIBE") != nullptr;      // tests: a grid the device cannot hold
+    if (over) a.MT = slots + 1;
+    a.spin_limit = 200000u;                     // ~50 ms: a workgroup that has to queue behind a resident one shows up as a time-out
+    int rc = launch_flow(a, d_args, m->flow_perh, true, true, nullptr);
+    hipError_t e = hipDeviceSynchronize();
+    unsigned h[2] = {0u, 0u};
+    if (e == hipSuccess) e = hipMemcpy(h, ctr, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d_args);
+    if (rc) return rc;
+    BVC_HIP_TRY(e);
+    m->flow_resident = h[0] == (unsigned)(ntg * a.MT) && h[1] == 0u;
+    return BVC_OK;
+}
 
 // All T frames of BVRNN.encode (encode = true) or BVRNN.decode in one launch.  w.part_dec0 (and w.part_gru for decode)
 // must hold the pre-computed halves; h0 may be null (zero state).
-int run_flow(const bvc_model *m, const Workspace &w, bool encode, const float *d_h0, int B, int64_t T, const float *d_bits,
+int run_flow(const bvc_model *m, const Workspace &w, bool encode, int chains, const float *d_h0, int B, int64_t T, const float *d_bits,
              float *d_codes, float *d_prob, float *d_all_h, float *d_mel, float *d_hT, hipStream_t s) {
     const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
     const int mt16 = ((B + 15) / 16) * 16;
     int rc;
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        BVC_HIP_TRY(hipStreamIsCapturing(s, &cs));
+        if (cs != hipStreamCaptureStatusNone) { set_error("the persistent recurrence cannot be captured into a graph"); return BVC_EINVAL; }
+    }
     if ((rc = launch_fill_u32(reinterpret_cast<unsigned *>(w.flow), FLOW_POISON, (long long)FB_COUNT * 2 * (long long)w.flow_slot, s))) return rc;
     float *h0p = flow_buf(w, FB_H, 0);
     if ((rc = launch_fill(h0p, 0.0f, (long long)mt16 * H, s))) return rc;
@@ -936,7 +1049,7 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, const float *d
     a.flow = w.flow;
     a.slot_bytes = (unsigned)(w.flow_slot * sizeof(float));
     a.B = B; a.MT = mt16 / 16; a.T = T;
-    a.MG = flow_chains(m, B);
+    a.MG = chains;
     a.NTG = (H > X ? (H > Z ? H : Z) : (X > Z ? X : Z)) / 16;
     a.part0 = w.part_dec0;
     a.part_gru = encode ? nullptr : w.part_gru;
@@ -945,14 +1058,17 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, const float *d
     a.var_bit = m->cfg.var_bit;
     a.status = m->d_status;
     { static const bool hot = getenv("BVC_FLOW_HOTW") != nullptr; a.dbg_hot_w = hot ? 1 : 0; }
-    a.spin_limit = 4000000u;                   // > 1 s of polling: only a workgroup that never became resident gets there
+    a.spin_limit = m->flow_spin_limit;
+    a.dbg_withhold = m->flow_debug_withhold;
     if (g_kprobe.enabled) {                    // bench instrumentation: per-layer entry / exit stamps of workgroup 0
         const int nodes = encode ? 14 : 8;
-        const size_t need = (size_t)2 * T * nodes;
+        const size_t need = (size_t)FLOW_STAMPS * T * nodes;
         if (need > g_kprobe.capacity) { set_error("kprobe buffer too small for T=%lld", (long long)T); return BVC_EINVAL; }
         BVC_HIP_TRY(hipMemsetAsync(g_kprobe.dev, 0, need * sizeof(unsigned long long), s));
         g_kprobe.T = T; g_kprobe.nodes = nodes;
         a.probe = g_kprobe.dev; a.probe_nodes = nodes; a.probe_first = encode ? 1 : 7;
+        a.probe_wg = getenv("BVC_PROBE_WG") ? atoi(getenv("BVC_PROBE_WG")) : 0;
+        a.probe_wave = getenv("BVC_PROBE_WAVE") ? atoi(getenv("BVC_PROBE_WAVE")) & 7 : 0;
     }
     {
         std::lock_guard<std::mutex> lk(g_flow_mu);
@@ -965,7 +1081,7 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, const float *d
         if (g_flow_n[dev] >= (unsigned long long)tickets) BVC_HIP_TRY(hipStreamWaitEvent(s, ev, 0));
         ProbeScope probe(PK_LINEAR, s);
         static const bool fill = !(getenv("BVC_FLOW_FILL") && getenv("BVC_FLOW_FILL")[0] == '0');
-        if ((rc = launch_flow(a, w.flow_args, m->flow_perh, encode, fill && a.MG == 1, s))) return rc;
+        if ((rc = launch_flow(a, w.flow_args, m->flow_perh, encode, fill && !m->flow_debug_nofill && a.MG == 1, s))) return rc;
         BVC_HIP_TRY(hipEventRecord(ev, s));
         ++g_flow_n[dev];
     }
@@ -999,23 +1115,24 @@ int batched_mlp3(const bvc_model *m, const Workspace &w, const Linear (&l)[3], c
     return launch_gemm_batched(w.pxB, H, l[2].w, H, l[2].b, BT, H, H, 1, w.pxA, H, s, GO_PACKED_FROM_UTT, T, mt16);
 }
 
-int run_encode(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_mel, const float *d_bits,
-               const float *d_h0, int B, int64_t T, float *d_codes, float *d_all_h, float *d_hT, float *d_prob,
-               hipStream_t s) {
+int run_encode_body(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_mel, const float *d_bits,
+                    const float *d_h0, int B, int64_t T, float *d_codes, float *d_all_h, float *d_hT, float *d_prob,
+                    hipStream_t s) {
     const int H = m->cfg.h_dim, X = m->cfg.num_mels;
     const long long BT = (long long)B * T;
     int rc;
     if (m->cfg.var_bit && !d_bits) { set_error("bits per frame required when var_bit=1"); return BVC_EINVAL; }
     // y = (y - mean) / std ; phi_x over all frames (bvrnn.py:173-178)
     if ((rc = launch_normalize_rows(d_mel, m->mean_mel, m->std_mel, BT, X, w.yn, s))) return rc;
-    if (flow_usable(m, B)) {
+    const int chains = flow_chains(m, B, s);
+    if (chains) {
         // ... and so is the phi_x half of enc.0 (bvrnn.py:189): part = enc.0[:, :H] phi_x(y_t) + b, all frames at once
         const int iBT = (int)BT;
         if ((rc = launch_gemm_batched(w.yn, X, m->phi_x[0].w, X, m->phi_x[0].b, iBT, H, X, 1, w.pxC, H, s))) return rc;
         if ((rc = launch_gemm_batched(w.pxC, H, m->phi_x[1].w, H, m->phi_x[1].b, iBT, H, H, 1, w.pxB, H, s))) return rc;
         if ((rc = launch_gemm_batched(w.pxB, H, m->phi_x[2].w, H, m->phi_x[2].b, iBT, H, H, 1, w.pxC, H, s))) return rc;
         if ((rc = launch_gemm_batched(w.pxC, H, m->enc[0].w, 2 * H, m->enc[0].b, iBT, H, H, 0, w.part_dec0, H, s))) return rc;
-        return run_flow(m, w, true, d_h0, B, T, d_bits, d_codes, d_prob, d_all_h, nullptr, d_hT, s);
+        return run_flow(m, w, true, chains, d_h0, B, T, d_bits, d_codes, d_prob, d_all_h, nullptr, d_hT, s);
     }
     if ((rc = batched_mlp3(m, w, m->phi_x, w.yn, X, B, T, s))) return rc;
     if ((rc = init_state(w, d_h0, B, H, s))) return rc;
@@ -1031,14 +1148,23 @@ int run_encode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     return BVC_OK;
 }
 
-int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_codes, const float *d_h0, int B,
-               int64_t T, float *d_mel, float *d_hT, hipStream_t s) {
+int run_encode(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_mel, const float *d_bits,
+               const float *d_h0, int B, int64_t T, float *d_codes, float *d_all_h, float *d_hT, float *d_prob,
+               hipStream_t s) {
+    const int rc = run_encode_body(m, w, ws_base, d_mel, d_bits, d_h0, B, T, d_codes, d_all_h, d_hT, d_prob, s);
+    const int rc2 = mark_call_end(s);
+    return rc ? rc : rc2;
+}
+
+int run_decode_body(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_codes, const float *d_h0, int B,
+                    int64_t T, float *d_mel, float *d_hT, hipStream_t s) {
     const int H = m->cfg.h_dim, Z = m->cfg.z_dim;
     int rc;
     // phi_z depends on the codes only: all frames at once, outside the recurrence (bvrnn.py:223)
     CallDesc d;
     memset(&d, 0, sizeof(d));
-    const bool flow = flow_usable(m, B);
+    const int chains = flow_chains(m, B, s);
+    const bool flow = chains > 0;
     const bool pre = flow || (m->precomp_pz && T >= PRECOMP_MIN_FRAMES);
     const int kind = pre ? STEP_DECODE_PRE : STEP_DECODE;
     if (pre) {
@@ -1051,7 +1177,7 @@ int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
         if ((rc = launch_gemm_batched(w.pxC, H, m->dec[0].w, 2 * H, m->dec[0].b, BT, H, H, 0, w.part_dec0, H, s))) return rc;
         if ((rc = launch_gemm_batched(w.pxC, H, m->w_ih_nat + H, 2 * H, m->b_ih, BT, 3 * H, H, 0, w.part_gru, 3 * H, s))) return rc;
         d.p[DS_PARTD] = w.part_dec0; d.p[DS_PARTG] = w.part_gru;
-        if (flow) return run_flow(m, w, false, d_h0, B, T, nullptr, nullptr, nullptr, nullptr, d_mel, d_hT, s);
+        if (flow) return run_flow(m, w, false, chains, d_h0, B, T, nullptr, nullptr, nullptr, nullptr, d_mel, d_hT, s);
     } else {
         if ((rc = batched_mlp3(m, w, m->phi_z, d_codes, Z, B, T, s))) return rc;
         d.p[DS_PZ] = w.pxA;
@@ -1063,6 +1189,13 @@ int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const floa
     if ((rc = run_recurrence(m, w, ws_base, B, T, kind, s))) return rc;
     if (d_hT && (rc = read_state(w, B, H, T, d_hT, s))) return rc;
     return BVC_OK;
+}
+
+int run_decode(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_codes, const float *d_h0, int B,
+               int64_t T, float *d_mel, float *d_hT, hipStream_t s) {
+    const int rc = run_decode_body(m, w, ws_base, d_codes, d_h0, B, T, d_mel, d_hT, s);
+    const int rc2 = mark_call_end(s);
+    return rc ? rc : rc2;
 }
 
 // ---- BVRNN.forward (bvrnn.py:86-160): the training-time pass, forward values only --------------------
@@ -1468,7 +1601,7 @@ int bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t n
     if ((rc = build_bvrnn(m.get(), tm))) return rc;
     {
         const char *rr = getenv("BVC_RECURRENCE");
-        m->use_flow = !(rr && strcmp(rr, "layers") == 0) && !m->side_branch;
+        m->recurrence = (rr && strcmp(rr, "layers") == 0) ? RS_LAYERS : (rr && strcmp(rr, "persistent") == 0) ? RS_PERSISTENT : RS_AUTO;
     }
     if ((rc = build_flow(m.get()))) return rc;
     if ((rc = build_vocoder(m.get(), tm))) return rc;
@@ -1501,6 +1634,7 @@ size_t bvc_workspace_bytes(const bvc_model *m, int32_t B, int64_t T) {
 
 int bvc_stft_logmel(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, float scale, float *d_mel,
                     void *stream) {
+    if (int st_ = sticky_status(m)) return st_;
     if (!m || !d_wav || !d_mel) { set_error("null argument"); return BVC_EINVAL; }
     const int64_t T = bvc_num_frames(m, L);
     if (B <= 0 || T <= 0) { set_error("input too short for reflect padding (L=%lld)", (long long)L); return BVC_EINVAL; }
@@ -1510,6 +1644,7 @@ int bvc_stft_logmel(const bvc_model *m, const float *d_wav, int32_t B, int64_t L
 int bvc_bvrnn_encode(const bvc_model *m, const float *d_mel, const float *d_bits, const float *d_h0, int32_t B,
                      int64_t T, float *d_codes, float *d_all_h, float *d_hT, float *d_prob, void *d_ws,
                      size_t ws_bytes, void *stream) {
+    if (int st_ = sticky_status(m)) return st_;
     Workspace w;
     int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
     if (rc) return rc;
@@ -1519,6 +1654,7 @@ int bvc_bvrnn_encode(const bvc_model *m, const float *d_mel, const float *d_bits
 
 int bvc_bvrnn_decode(const bvc_model *m, const float *d_codes, const float *d_h0, int32_t B, int64_t T, float *d_mel,
                      float *d_hT, void *d_ws, size_t ws_bytes, void *stream) {
+    if (int st_ = sticky_status(m)) return st_;
     Workspace w;
     int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
     if (rc) return rc;
@@ -1529,6 +1665,7 @@ int bvc_bvrnn_decode(const bvc_model *m, const float *d_codes, const float *d_h0
 int bvc_bvrnn_forward(const bvc_model *m, const float *d_mel, const float *d_bits, const uint8_t *h_use_gen,
                       int32_t update_h, int32_t update_h2, const float *d_noise, int32_t B, int64_t T, float *d_dec,
                       float *d_kld, float *d_z, float *d_prob, float *d_prior, void *d_ws, size_t ws_bytes, void *stream) {
+    if (int st_ = sticky_status(m)) return st_;
     Workspace w;
     int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
     if (rc) return rc;
@@ -1545,6 +1682,7 @@ int bvc_bvrnn_forward(const bvc_model *m, const float *d_mel, const float *d_bit
 
 int bvc_bigvgan(const bvc_model *m, const float *d_mel, int32_t B, int64_t T, int64_t length, float out_scale_div,
                 float *d_wav, void *d_ws, size_t ws_bytes, void *stream) {
+    if (int st_ = sticky_status(m)) return st_;
     Workspace w;
     int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
     if (rc) return rc;
@@ -1555,6 +1693,7 @@ int bvc_bigvgan(const bvc_model *m, const float *d_mel, int32_t B, int64_t T, in
 
 int bvc_encode(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, float scale, float bits_per_frame,
                float *d_codes, void *d_ws, size_t ws_bytes, void *stream) {
+    if (int st_ = sticky_status(m)) return st_;
     if (!m) { set_error("null model"); return BVC_EINVAL; }
     const int64_t T = bvc_num_frames(m, L);
     if (T <= 0) { set_error("input too short for reflect padding (L=%lld)", (long long)L); return BVC_EINVAL; }
@@ -1570,6 +1709,7 @@ int bvc_encode(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, flo
 
 int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, int64_t length, float out_scale_div,
                float *d_wav, void *d_ws, size_t ws_bytes, void *stream) {
+    if (int st_ = sticky_status(m)) return st_;
     Workspace w;
     int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
     if (rc) return rc;
@@ -1769,9 +1909,24 @@ int bvc_stream_codec_tick(bvc_stream_codec *st, int32_t *n_frames, void *stream)
 
 int bvc_model_set_option(bvc_model *m, const char *name, int32_t value) {
     if (!m || !name) { set_error("bvc_model_set_option: null argument"); return BVC_EINVAL; }
-    if (strcmp(name, "recurrence") == 0) {                 // 0: persistent kernel (one batch at a time), 1: launch per layer
-        if (value != 0 && value != 1) { set_error("bvc_model_set_option: recurrence must be 0 or 1"); return BVC_EINVAL; }
-        m->use_flow = value == 0 && !m->side_branch;
+    if (strcmp(name, "recurrence") == 0) {
+        // 0: persistent kernel for every call, 1: one launch per layer for every call, 2 (default): automatic - persistent while
+        // calls come one at a time, launch per layer while calls of several streams overlap (see flow_chains)
+        if (value < 0 || value > 2) { set_error("bvc_model_set_option: recurrence must be 0 (persistent), 1 (layers) or 2 (auto)"); return BVC_EINVAL; }
+        m->recurrence = value;
+        return BVC_OK;
+    }
+    if (strcmp(name, "flow_spin_limit") == 0) {            // polls before a wait inside the persistent kernel gives up (tests)
+        if (value < 1) { set_error("bvc_model_set_option: flow_spin_limit must be positive"); return BVC_EINVAL; }
+        m->flow_spin_limit = (unsigned)value;
+        return BVC_OK;
+    }
+    if (strcmp(name, "flow_debug_withhold") == 0) {        // tests only: workgroup 0 of every persistent launch does nothing
+        m->flow_debug_withhold = value != 0;
+        return BVC_OK;
+    }
+    if (strcmp(name, "flow_debug_nofill") == 0) {          // tests only: the layer program without filler quanta
+        m->flow_debug_nofill = value != 0;
         return BVC_OK;
     }
     if (strcmp(name, "vocoder_full_tiles") == 0) {         // 1 (default): C = 8 AMP pairs on the two-rows-per-tile kernel; 0: generic kernel.
@@ -1782,13 +1937,23 @@ int bvc_model_set_option(bvc_model *m, const char *name, int32_t value) {
     return BVC_EINVAL;
 }
 
+int bvc_model_get_option(const bvc_model *m, const char *name, int32_t *value) {
+    if (!m || !name || !value) { set_error("bvc_model_get_option: null argument"); return BVC_EINVAL; }
+    if (strcmp(name, "recurrence") == 0) { *value = m->recurrence; return BVC_OK; }
+    if (strcmp(name, "flow_resident") == 0) { *value = m->flow_resident ? 1 : 0; return BVC_OK; }       // result of the residency census
+    if (strcmp(name, "flow_supported") == 0) { *value = m->flow_perh > 0 ? 1 : 0; return BVC_OK; }    // h_dim laid out for the persistent kernel
+    if (strcmp(name, "compute_units") == 0) { *value = m->cu_count; return BVC_OK; }
+    set_error("bvc_model_get_option: unknown option '%s'", name);
+    return BVC_EINVAL;
+}
+
 int bvc_model_status(const bvc_model *m, uint32_t *code) {
     if (!m) { set_error("null model"); return BVC_EINVAL; }
     unsigned v = 0;
-    if (m->d_status) {
+    if (m->h_status) {
         BVC_HIP_TRY(hipDeviceSynchronize());
-        BVC_HIP_TRY(hipMemcpy(&v, m->d_status, sizeof(v), hipMemcpyDeviceToHost));
-        if (v) BVC_HIP_TRY(hipMemset(m->d_status, 0, sizeof(v)));
+        v = *m->h_status;
+        if (v) *m->h_status = 0u;
     }
     if (code) *code = v;
     if (v) {
@@ -1861,7 +2026,7 @@ int bvc_unpack_codes(const uint8_t *d_bytes, int32_t B, int64_t T, int32_t z_dim
 
 int bvc_kprobe_enable(int32_t on) {
     if (on && !g_kprobe.dev) {
-        const size_t cap = (size_t)2 * 16 * 4096;               // up to 4096 frames x 16 nodes
+        const size_t cap = (size_t)FLOW_STAMPS * 16 * 4096;     // up to 4096 frames x 16 nodes (x stamp kinds of the persistent kernel)
         BVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g_kprobe.dev), cap * sizeof(unsigned long long)));
         g_kprobe.capacity = cap;
     }
@@ -1881,6 +2046,37 @@ int bvc_kprobe_read(int32_t node_lo, int32_t node_hi, double *mean_us, double *m
             for (int k = node_lo; k < node_hi && k < g_kprobe.nodes; ++k) {
                 const unsigned long long a = h[t * g_kprobe.nodes + k], b = h[cnt / 2 + t * g_kprobe.nodes + k];
                 if (b <= a) continue;
+                const double us = (double)(b - a) * 0.01;        // 100 MHz ticks
+                sum += us; if (us < mn) mn = us; ++n;
+            }
+    }
+    if (mean_us) *mean_us = n ? sum / n : 0.0;
+    if (min_us) *min_us = n ? mn : 0.0;
+    if (n_samples) *n_samples = n;
+    return BVC_OK;
+}
+
+// Raw stamps of the persistent recurrence's probing wave: mean / min of (stamp kind `to` - stamp kind `from`) over the frames,
+// for the layers [node_lo, node_hi).  from = -1: `to` of layer k against stamp 1 (published) of layer k - 1, i.e. since the
+// previous layer's output left.
+int bvc_kprobe_read_span(int32_t from, int32_t to, int32_t node_lo, int32_t node_hi, double *mean_us, double *min_us, int32_t *n_samples) {
+    BVC_HIP_TRY(hipDeviceSynchronize());
+    double sum = 0.0, mn = 1e30;
+    int n = 0;
+    if (from < -1 || from >= FLOW_STAMPS || to < 0 || to >= FLOW_STAMPS) { set_error("bvc_kprobe_read_span: stamp kinds are 0..%d", FLOW_STAMPS - 1); return BVC_EINVAL; }
+    if (g_kprobe.dev && g_kprobe.T > 0 && (size_t)FLOW_STAMPS * g_kprobe.T * g_kprobe.nodes <= g_kprobe.capacity) {
+        const size_t per = (size_t)g_kprobe.T * g_kprobe.nodes, cnt = (size_t)FLOW_STAMPS * per;
+        std::vector<unsigned long long> h(cnt);
+        BVC_HIP_TRY(hipMemcpy(h.data(), g_kprobe.dev, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (long long t = 0; t < g_kprobe.T; ++t)
+            for (int k = node_lo; k < node_hi && k < g_kprobe.nodes; ++k) {
+                unsigned long long a;
+                if (from >= 0) a = h[(size_t)from * per + t * g_kprobe.nodes + k];
+                else if (k > 0) a = h[per + t * g_kprobe.nodes + k - 1];
+                else if (t > 0) a = h[per + (t - 1) * g_kprobe.nodes + g_kprobe.nodes - 1];
+                else continue;
+                const unsigned long long b = h[(size_t)to * per + t * g_kprobe.nodes + k];
+                if (!a || b <= a) continue;
                 const double us = (double)(b - a) * 0.01;        // 100 MHz ticks
                 sum += us; if (us < mn) mn = us; ++n;
             }

@@ -37,6 +37,33 @@ namespace {
 #ifndef BVC_GRU_ROUNDS_FILL
 #define BVC_GRU_ROUNDS_FILL 4      // rounds in which the GRU layer's remaining weights (phi_x third) pass through the registers
 #endif
+// Experiments (compile-time, see tools/flow_variants.sh):
+//   BVC_FLOW_EARLYW    1: the next layer's weights are requested right behind this layer's operand requests (they then travel
+//                         under the products, the reduction and the epilogue and have landed when the next wait begins)
+//   BVC_FLOW_PREPOLL   1: (pipelined fillers) the first poll of the next layer's flags is requested BEFORE the quantum's weights, so
+//                         that it does not return behind them (a wave's loads return in order)
+//   BVC_FLOW_PARTNER_WAIT 1: the wave that shares wave 0's SIMD (wave 4) starts its quantum's products only once wave 0 has
+//                         issued the publishing store (its MFMAs take issue slots from the epilogue)
+// (Measured and dropped: two or three flag polls in flight per wave - 57.9 / 59.2 against 55.7 ms per step: the polls themselves
+// load the hand-off path.)
+//   BVC_FLOW_DIAG      1: the probing lane also stamps flags-seen / products-done / barrier-passed (tools/flow_probe.py --diag)
+#ifndef BVC_FLOW_EARLYW
+#define BVC_FLOW_EARLYW 0
+#endif
+#ifndef BVC_FLOW_PREPOLL
+#define BVC_FLOW_PREPOLL 0
+#endif
+#ifndef BVC_FLOW_PARTNER_WAIT
+#define BVC_FLOW_PARTNER_WAIT 0
+#endif
+#ifndef BVC_FLOW_DIAG
+#define BVC_FLOW_DIAG 0
+#endif
+//   BVC_FLOW_STASH     1: a wave keeps the operand blocks the filler quanta multiply (h, phi_z: fetched and verified for the layer that
+//                         consumes them first) in LDS, so a quantum requests its weights only
+#ifndef BVC_FLOW_STASH
+#define BVC_FLOW_STASH (BVC_FILL_ORDER >= 3)
+#endif
 constexpr int AUX_SC1 = 16;
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -44,6 +71,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 __device__ __forceinline__ float elu1(float v) { return v > 0.0f ? v : expf(v) - 1.0f; }
 __device__ __forceinline__ float sigmoid1(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// the status word lives in host-mapped pinned memory (the host reads it without synchronising): a plain system-scope store
+__device__ __forceinline__ void flow_report(unsigned *status, unsigned code) {
+    __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 struct FlowWg {
     __amdgpu_buffer_rsrc_t rs;       // the flow region
@@ -67,22 +99,34 @@ struct FlowSrc { unsigned base, vl; };     // scalar byte offset of this wave's 
 // producer block and poll).  A flag can be visible before the rest of its block: the consumer still verifies what it fetches.
 template <int PER>
 __device__ __forceinline__ FlowSrc flow_wait(const FlowWg &g, unsigned buf, int nbdim, int kb0, bool &give_up, unsigned code,
-                                             unsigned &spins) {
+                                             unsigned &spins, const unsigned *pre = nullptr) {
     FlowSrc s;
     // uniform part of every address in the scalar offset, lane part in one shared VGPR
     s.base = __builtin_amdgcn_readfirstlane(buf + (unsigned)(g.mtile * nbdim + kb0) * 1024u);
     s.vl = (unsigned)g.lane * 16u;
     const unsigned fl = (unsigned)(g.lane < PER ? g.lane : PER - 1) * 1024u + 63u * 16u + 12u;
+    if (pre) {                                             // a poll requested at the end of the previous layer (BVC_FLOW_PREPOLL)
+        const unsigned t = *pre;
+        if (!__any(t == FLOW_POISON)) return s;
+    }
     while (!give_up) {
         const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(g.rs, fl, s.base, AUX_SC1);
         if (!__any(t == FLOW_POISON)) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > g.spin_limit) {
             give_up = true;
-            if (g.lane == 0) atomicExch(g.status, code);
+            if (g.lane == 0) flow_report(g.status, code);
         }
     }
     return s;
+}
+
+// one poll of the flags of blocks [kb0, kb0 + PER), requested without waiting for it (flow_wait looks at it first)
+template <int PER>
+__device__ __forceinline__ unsigned flow_prepoll(const FlowWg &g, unsigned buf, int nbdim, int kb0) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(buf + (unsigned)(g.mtile * nbdim + kb0) * 1024u);
+    const unsigned fl = (unsigned)(g.lane < PER ? g.lane : PER - 1) * 1024u + 63u * 16u + 12u;
+    return __builtin_amdgcn_raw_buffer_load_b32(g.rs, fl, base, AUX_SC1);
 }
 
 template <int PER>
@@ -104,10 +148,22 @@ __device__ __forceinline__ f32x4 wload(GPtr ub, unsigned lane16, int blk) {
     return *reinterpret_cast<const f32x4 __attribute__((address_space(1))) *>(ub + lane16 + (unsigned)blk * 1024u);
 }
 
+// What a layer wants done between a segment's operand requests and its products: the next layer's weights requested
+// (BVC_FLOW_EARLYW), diagnostic stamps taken.
+typedef u32x4 __attribute__((address_space(3))) *LdsX;      // this wave's stash of operand blocks in LDS: [k-block][lane]
+struct SegHook {
+    const float *nw; int nwnb; bool pre;           // next layer's packed weights, k-blocks per row; request them here?
+    unsigned long long *st_flags, *st_done;       // BVC_FLOW_DIAG: where to stamp "flags seen" / "products done" (or null)
+    LdsX stash;                                    // BVC_FLOW_STASH: keep the verified operand blocks of this segment there (or null)
+    const unsigned *polled;                        // BVC_FLOW_PREPOLL: a poll of this segment's flags that is already on its way (or null)
+};
+__device__ __forceinline__ SegHook no_hook() { return SegHook{nullptr, 0, false, nullptr, nullptr, (LdsX)0, nullptr}; }
+
 // acc += W[ntile rows][segment] . X[segment]   for this wave's share of the segment's k-blocks
-template <int PER>
+template <int PER, int PERN>
 __device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int wnb, int nb, unsigned buf, bool w_ready,
-                                            f32x4 (&wv)[PER], f32x4 &acc, bool &give_up, unsigned code, int kb_off = 0) {
+                                            f32x4 (&wv)[PER], f32x4 &acc, bool &give_up, unsigned code, int kb_off,
+                                            const SegHook &hk, f32x4 (&wn)[PERN]) {
     const int kb0 = kb_off + g.wave * PER;
     if (PER == 1 && kb0 >= nb) return;                     // wave-uniform: fewer k-blocks than waves
     if (!w_ready) {
@@ -116,14 +172,21 @@ __device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int
         for (int u = 0; u < PER; ++u) wv[u] = wload(ub, (unsigned)g.lane * 16u, u);
     }
     unsigned spins = 0;
-    const FlowSrc src = flow_wait<PER>(g, buf, nb, kb0, give_up, code, spins);
+    const FlowSrc src = flow_wait<PER>(g, buf, nb, kb0, give_up, code, spins, hk.polled);
+    if (BVC_FLOW_DIAG && hk.st_flags) *hk.st_flags = __builtin_amdgcn_s_memrealtime();
     const f32x4 acc_in = acc;
-    bool again;
+    bool again, first = true;
     do {
         // The blocks are multiplied as they arrive (the loads return in order); whether one of them still held the
         // sentinel is only known at the end: then the products are thrown away and everything is fetched again.
         u32x4 xr[PER];
         flow_issue<PER>(g, src, xr);
+        if (hk.pre && first) {                             // behind the operand requests: nothing this layer waits for queues behind them
+            const GPtr ub = uniform_ptr(hk.nw, ((size_t)g.ntile * hk.nwnb + g.wave * PERN) * g.wmul);
+#pragma unroll
+            for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)g.lane * 16u, u);
+        }
+        first = false;
         f32x4 a2 = acc_in;
         bool bad = false;
 #pragma unroll
@@ -134,12 +197,24 @@ __device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int
             for (int e = 0; e < 4; ++e) a2 = mfma16(wv[u][e], xv[e], a2);
         }
         again = __any(bad) && !give_up;
-        if (!again) acc = a2;
-        else if (++spins > g.spin_limit) {
+        if (!again) {
+            acc = a2;
+            if (BVC_FLOW_STASH && hk.stash) {
+#pragma unroll
+                for (int u = 0; u < PER; ++u) hk.stash[(kb_off / 8 * PER + u) * 64 + g.lane] = xr[u];
+            }
+        } else if (++spins > g.spin_limit) {
             give_up = true;
-            if (g.lane == 0) atomicExch(g.status, code);
+            if (g.lane == 0) flow_report(g.status, code);
         }
     } while (again);
+    if (BVC_FLOW_DIAG && hk.st_done) *hk.st_done = __builtin_amdgcn_s_memrealtime();
+}
+template <int PER>
+__device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int wnb, int nb, unsigned buf, bool w_ready,
+                                            f32x4 (&wv)[PER], f32x4 &acc, bool &give_up, unsigned code, int kb_off = 0) {
+    f32x4 none[1];
+    lin_segment<PER, 1>(g, w, wnb, nb, buf, w_ready, wv, acc, give_up, code, kb_off, no_hook(), none);
 }
 
 // One round of a GRU segment: HALF k-blocks x 3 gates of weights (gate-interleaved [n/16][k/16][gate][lane][4]).
@@ -188,7 +263,7 @@ __device__ __forceinline__ void gru_fetch_fresh(const FlowWg &g, unsigned buf, i
         again = __any(bad) && !give_up;
         if (again && ++spins > g.spin_limit) {
             give_up = true;
-            if (g.lane == 0) atomicExch(g.status, code);
+            if (g.lane == 0) flow_report(g.status, code);
         }
     } while (again);
 }
@@ -204,20 +279,28 @@ __device__ __forceinline__ bool fill_active(const FlowWg &g, const FlowFill &f) 
 }
 template <int PER, int GATE>
 __device__ __forceinline__ void fill_issue(const FlowWg &g, const FlowFill &f, f32x4 (&wv)[PER], u32x4 (&xr)[PER]) {
-    if (!fill_active<PER, GATE>(g, f)) return;
+    if (!fill_active<PER, GATE>(g, f)) {                   // (defined on every path: no stale value stays live across the frame loop)
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { wv[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; xr[u] = (u32x4){0u, 0u, 0u, 0u}; }
+        return;
+    }
     const int kb0 = g.wave * PER;
     const unsigned l16 = (unsigned)g.lane * 16u;
     const GPtr ub = uniform_ptr(f.w, (GATE >= 0 ? ((size_t)g.ntile * f.wnb + kb0) * 3 + GATE : (size_t)g.ntile * f.wnb + kb0) * g.wmul);
 #pragma unroll
     for (int u = 0; u < PER; ++u) wv[u] = wload(ub, l16, GATE >= 0 ? u * 3 : u);
-    gru_issue_known<PER>(g, f.buf, f.nb, xr);
+    if (!BVC_FLOW_STASH) gru_issue_known<PER>(g, f.buf, f.nb, xr);
 }
 template <int PER, int GATE>
-__device__ __forceinline__ void fill_multiply(const FlowWg &g, const FlowFill &f, const f32x4 (&wv)[PER], const u32x4 (&xr)[PER], f32x4 &acc) {
+__device__ __forceinline__ void fill_multiply(const FlowWg &g, const FlowFill &f, const f32x4 (&wv)[PER], const u32x4 (&xr)[PER], f32x4 &acc,
+                                              LdsX stash) {
     if (!fill_active<PER, GATE>(g, f)) return;
+    u32x4 xs[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) xs[u] = BVC_FLOW_STASH ? stash[u * 64 + g.lane] : xr[u];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        const f32x4 xv = __builtin_bit_cast(f32x4, xr[u]);
+        const f32x4 xv = __builtin_bit_cast(f32x4, xs[u]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma16(wv[u][e], xv[e], acc);
     }
@@ -249,6 +332,10 @@ struct FlowCtx {
     FlowWg g;
     FlowArgsC a;
     float *red_lin, *red_gru;
+    LdsX stash;              // BVC_FLOW_STASH: this wave's operand blocks of the quanta's input
+    unsigned prepoll;        // BVC_FLOW_PREPOLL: result of the poll requested at the end of the previous layer ...
+    bool has_prepoll;        // ... if there is one
+    volatile unsigned __attribute__((address_space(3))) *pubflag;      // BVC_FLOW_PARTNER_WAIT: hop count of wave 0's last publishing store
     unsigned par;            // frame parity
     long long t, fr;         // frame; (utterance, frame) index of this lane's row
     int row;
@@ -262,10 +349,16 @@ struct FlowCtx {
     f32x4 fgh[3], fgi[3], fd0;
 };
 
-__device__ __forceinline__ void flow_stamp(const FlowCtx &c, int hopid, int which) {
-    if (!c.probe) return;
+__device__ __forceinline__ unsigned long long *flow_stamp_slot(const FlowCtx &c, int hopid, int which) {
+    if (!c.probe) return nullptr;
     const auto &a = *c.a;
-    a.probe[((long long)which * a.T + c.t) * a.probe_nodes + (hopid - a.probe_first)] = __builtin_amdgcn_s_memrealtime();
+    return a.probe + ((long long)which * a.T + c.t) * a.probe_nodes + (hopid - a.probe_first);
+}
+// which: 0 layer entered, 1 output published (wave 0); BVC_FLOW_DIAG: 2 flags of the (last) segment seen, 3 its products done,
+// 4 barrier passed, 5 layer left (behind the filler quantum)
+__device__ __forceinline__ void flow_stamp(const FlowCtx &c, int hopid, int which) {
+    unsigned long long *p = flow_stamp_slot(c, hopid, which);
+    if (p) *p = __builtin_amdgcn_s_memrealtime();
 }
 
 // Wave 0 of a workgroup, after the barrier: sum the waves' partial tiles (fixed order), apply the layer's epilogue and publish the
@@ -292,7 +385,7 @@ __device__ __forceinline__ void flow_publish(const FlowCtx &c, int hopid, const 
         for (int j = 0; j < 4; ++j) {
             pr[j] = sigmoid1(v[j]);
             float z = rintf(pr[j]);                    // round half to even (torch.round)
-            if (a.var_bit) z = (bitsv > (float)(n0 + j)) ? z : 0.5f;
+            if (a.var_bit) z = (bitsv > (float)(n0 + j)) ? z : (z != z ? z : 0.5f);    // z*m + 0.5*(1-m): NaN * 0 is NaN (bvrnn.py:193-194)
             o[j] = z;
         }
         if (c.rowok) {
@@ -320,23 +413,38 @@ __device__ __forceinline__ void flow_publish(const FlowCtx &c, int hopid, const 
 // One layer: y = epi( sum_s W_s . x_s + bias [+ addend] ).  PER k-blocks per wave and segment (compile time), one or
 // two segments (the one whose input is produced last comes last), PRE_IN: wv already holds segment 0's weights,
 // PRE_OUT: request `nxt`'s weights (PERN blocks per wave) into wn before the reduction.
-template <int PER, int EPI, bool TWO, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H = false, int FGATE = -2, int NW = 8>
+// BVC_FILL_ORDER >= 3 ("pipelined fillers"): a quantum's operands are requested BEHIND the layer's publishing store (nothing but
+// the layer's own operand requests sits in the compute unit's in-order request queue in front of the reduction barrier and the
+// store: 1 KiB per wave-instruction is taken at 64 B per clock, so 24 KiB per wave in front of the barrier hold every wave - and
+// the store - back by more than a microsecond) and MULTIPLIED a layer later, behind that layer's reduction barrier, in the shadow
+// of its epilogue and hand-off.  The operands wait in the pend registers (PEND: this layer multiplies the quantum the previous
+// one requested).  3: a second workgroup barrier keeps the other waves' requests behind wave 0's store; 4: no second barrier.
+// NSRC: (BVC_FLOW_PREPOLL) the buffer the NEXT layer waits for first, if it is an h_dim-wide one (else -1).
+template <int PER, int EPI, bool TWO, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H = false, int FGATE = -2, int NW = 8,
+          bool PEND = false, int NSRC = -1>
 __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin l0, int src0, const FlowLin l1, int src1,
                                            int nb, int ntiles, int out, f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN],
+                                           f32x4 (&pw)[PERN], u32x4 (&px)[PERN],
                                            const f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, const FlowFill fill = FlowFill{nullptr, 0, 0, 0u},
-                                           f32x4 *facc = nullptr) {
+                                           f32x4 *facc = nullptr, f32x4 *pacc = nullptr) {
     const FlowWg &g = c.g;
     const auto &a = *c.a;
+    constexpr bool PIPE = BVC_FILL_ORDER >= 3;
     f32x4 fw[PERN];
     u32x4 fx[PERN];
+    const FlowFill pfill = {nullptr, 0, a.hb, 0u};         // (every quantum has h_dim inputs and outputs)
     if (g.ntile >= ntiles) {                               // uniform per workgroup (layers narrower than h_dim)
         if (PRE_OUT && c.pre_now) {
 #pragma unroll
             for (int u = 0; u < PERN; ++u) wn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};      // defined on every path: no value lives across the layer
         }
-        if (FGATE != -2) {                                 // nothing else to do in this layer: the whole quantum right away
+        c.has_prepoll = false;                             // (a poll requested for this layer's input: not this workgroup's business)
+        if (PIPE) {
+            if (PEND) fill_multiply<PERN, 0>(g, pfill, pw, px, *pacc, c.stash);
+            if (FGATE != -2) fill_issue<PERN, FGATE>(g, fill, pw, px);
+        } else if (FGATE != -2) {                          // nothing else to do in this layer: the whole quantum right away
             fill_issue<PERN, FGATE>(g, fill, fw, fx);
-            fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc);
+            fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc, c.stash);
         }
         return;
     }
@@ -358,14 +466,31 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
         }
     }
     f32x4 acc = acc0;
+    // EARLYW: the next layer's weights are requested inside the (last) segment, right behind its operand requests
+    constexpr bool EARLY = BVC_FLOW_EARLYW && PRE_OUT && PER > 1;
+    SegHook hk = no_hook();
+    if (BVC_FLOW_DIAG) { hk.st_flags = flow_stamp_slot(c, hopid, 2); hk.st_done = flow_stamp_slot(c, hopid, 3); }
+    // the layer behind which the first quantum of a product is requested is the one that fetches that product's input
+    if (BVC_FLOW_STASH && FGATE == 0) hk.stash = c.stash;
+    if (BVC_FLOW_PREPOLL && PER > 1 && !TWO && c.has_prepoll) hk.polled = &c.prepoll;
+    c.has_prepoll = false;
     if (PER == 1) {                                        // a narrow input (<= 8 k-blocks): one block per wave and pass
         for (int off = 0; off < nb; off += NW)
-            lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, off);
+            lin_segment<PER, PERN>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, off, hk, wn);
+        if (TWO)                                           // (h_dim <= 128 without filler quanta: dec.0 of encode has both halves here)
+            for (int off = 0; off < nb; off += NW)
+                lin_segment<PER, PERN>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, off, hk, wn);
     } else {
-        lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code);
-        if (TWO) lin_segment<PER>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code);
+        SegHook hl = hk;
+        if (EARLY) { hl.nw = nxt.w; hl.nwnb = nxt.wnb; hl.pre = c.pre_now; }
+        if (TWO) {
+            lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code);
+            lin_segment<PER, PERN>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, 0, hl, wn);
+        } else {
+            lin_segment<PER, PERN>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code, 0, hl, wn);
+        }
     }
-    if (PRE_OUT && c.pre_now) {                            // the next layer's weights travel during the reduction and the wait
+    if (PRE_OUT && !EARLY && c.pre_now) {                  // the next layer's weights travel during the reduction and the wait
         const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
@@ -375,14 +500,34 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
     // waves behind the store.  Measured 56.4 / 56.8 / 59.1 ms per step: behind the store the layer spans get 1 us shorter
     // (tools/flow_probe.py), but the filler's own fetch is then exposed behind the layer instead of travelling under its reduction.
     // (Requested earlier still - right behind the layer's own operand requests - the layers get slower: 53.9 vs 49.3 us per frame.)
-    if (FGATE != -2 && (BVC_FILL_ORDER == 0 || (BVC_FILL_ORDER == 1 && wave != 0))) fill_issue<PERN, FGATE>(g, fill, fw, fx);
+    if (!PIPE && FGATE != -2 && (BVC_FILL_ORDER == 0 || (BVC_FILL_ORDER == 1 && wave != 0))) fill_issue<PERN, FGATE>(g, fill, fw, fx);
     float *r = c.red_lin + (c.hopctr & 1u) * (NW * 256);
     ++c.hopctr;
     *reinterpret_cast<f32x4 *>(r + (wave * 64 + lane) * 4) = acc;
     __syncthreads();
-    if (wave == 0) flow_publish<EPI, ADD, REARM_H, NW>(c, hopid, r, n0, ytile, ntiles, out, bias4, add4, mean4, std4, bitsv);
-    if (FGATE != -2 && (BVC_FILL_ORDER == 2 || (BVC_FILL_ORDER == 1 && wave == 0))) fill_issue<PERN, FGATE>(g, fill, fw, fx);
-    if (FGATE != -2) fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc);
+    if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 4);
+    if (wave == 0) {
+        flow_publish<EPI, ADD, REARM_H, NW>(c, hopid, r, n0, ytile, ntiles, out, bias4, add4, mean4, std4, bitsv);
+        if (BVC_FLOW_PARTNER_WAIT && NW == 8 && (PEND || (!PIPE && FGATE != -2))) *c.pubflag = c.hopctr;
+    } else if (BVC_FLOW_PARTNER_WAIT && NW == 8 && wave == 4 && (PEND || (!PIPE && FGATE != -2))) {
+        // waves 0 and 4 share a SIMD: this wave's MFMAs would take issue slots from the epilogue everybody is waiting for
+        for (int i = 0; i < 4096 && *c.pubflag != c.hopctr; ++i) __builtin_amdgcn_s_sleep(2);
+    }
+    if (PIPE) {
+        if (PEND) fill_multiply<PERN, 0>(g, pfill, pw, px, *pacc, c.stash);      // requested a layer ago: long arrived
+        if (FGATE != -2) {
+            if (BVC_FILL_ORDER == 3) __syncthreads();      // wave 0's store is in the queue: the requests go behind it
+            if (BVC_FLOW_PREPOLL && NSRC >= 0) {           // the next layer's first poll goes in front of the quantum's requests
+                c.prepoll = flow_prepoll<PERN>(g, (unsigned)(NSRC * 2 + c.par) * a.slot_bytes, a.hb, wave * PERN);
+                c.has_prepoll = true;
+            }
+            fill_issue<PERN, FGATE>(g, fill, pw, px);
+        }
+    } else {
+        if (FGATE != -2 && (BVC_FILL_ORDER == 2 || (BVC_FILL_ORDER == 1 && wave == 0))) fill_issue<PERN, FGATE>(g, fill, fw, fx);
+        if (FGATE != -2) fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc, c.stash);
+    }
+    if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 5);
 }
 
 // MULTI: one single-segment layer for ALL chains of this workgroup, software-pipelined across the chains: while chain ci is
@@ -460,7 +605,7 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
             for (int u = 0; u < PER; ++u) bad |= is_poison4(xc[u]);
             if (++spins > g.spin_limit) {
                 c.give_up = true;
-                if (lane == 0) atomicExch(g.status, code);
+                if (lane == 0) flow_report(g.status, code);
             }
         }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -632,6 +777,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     c.a = ap;
     c.red_lin = lds;
     c.red_gru = lds + 2 * NW * 256;
+    c.stash = (LdsX)(lds + 2 * NW * 256 + NW * 6 * 256) + (tid >> 6) * (PERH * 64);     // (FILL kernels only: FLOW_LDS_FILL)
+    c.pubflag = (volatile unsigned __attribute__((address_space(3))) *)(lds + 2 * NW * 256 + NW * 6 * 256 + NW * 8 * 256);     // (behind the stashes)
+    c.has_prepoll = false;
+    c.prepoll = 0u;
+    if (FILL && BVC_FLOW_PARTNER_WAIT && tid == 0) *c.pubflag = 0xFFFFFFFFu;
     c.g.lane = tid & 63;
     c.g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
@@ -642,6 +792,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     const int mt0 = (slot % MTG) * MG;
     const int nch = MULTI ? (MT - mt0 < MG ? MT - mt0 : MG) : 1;
     c.g.mtile = mt0;
+    if (ap->census) {                                      // residency census (bvc_model_create): are all workgroups of this grid resident at once?
+        if (tid == 0) {
+            unsigned *ctr = ap->census;
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > ap->spin_limit) {            // bounded: a workgroup queued behind a resident one never lets the count complete
+                    __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        return;
+    }
+    if (ap->dbg_withhold && bid == 0) return;              // tests: a workgroup that never publishes (its consumers time out)
     if (c.g.ntile >= ap->NTG) return;                      // grid is rounded up to a multiple of 8 feature tiles
     c.g.rs = __builtin_amdgcn_make_buffer_rsrc(ap->flow, 0, (int)(FB_COUNT * 2u * ap->slot_bytes), 0x00020000);
     c.g.spin_limit = ap->spin_limit;
@@ -652,12 +818,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     c.give_up = false;
     c.pre_now = true;
     c.gructr = 0;
-    c.probe = ap->probe != nullptr && bid == 0 && tid == 0;
+    c.probe = ap->probe != nullptr && bid == ap->probe_wg && tid == ap->probe_wave * 64;
     c.hopctr = 0;
     const int hb = ap->hb, zb = ap->zb, xb = ap->xb;
     const long long T = ap->T;
     const bool hfull = c.g.ntile < hb;                     // this workgroup owns a tile of the h_dim-wide layers
     f32x4 wa[PERH], wb[PERH], w1[1];
+    f32x4 pfw[PERH];                                       // pipelined fillers: operands of the quantum requested behind the previous layer
+    u32x4 pfx[PERH];
     {
         const FlowLin first = ENCODE ? L(ap->enc0h) : L(ap->dec0h);
         const GPtr ub = uniform_ptr(first.w, hfull ? (size_t)c.g.ntile * first.wnb + c.g.wave * PERH : 0);
@@ -684,33 +852,38 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
         constexpr int G0 = FILL ? 0 : -2, G1 = FILL ? 1 : -2, G2 = FILL ? 2 : -2, GP = FILL ? -1 : -2;
         const FlowFill f_hh = {a.w_hh, hb, hb, hsrc}, f_d0 = {a.dec0h.w, a.dec0h.wnb, hb, hsrc}, f_iz = {a.w_ihz, 2 * hb, hb, zsrc};
         if constexpr (!MULTI) {
+            // pipelined fillers (BVC_FILL_ORDER >= 3): P marks the layers that multiply the quantum requested behind the previous layer
+            constexpr bool P = FILL && BVC_FILL_ORDER >= 3;
+#define PENDING(accp) (P ? accp : nullptr)
             if (ENCODE) {
-                //         PER   epilogue  two    add    pre_in pre_out       rearm  filler
-                flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb, zero4, f_hh, &c.fgh[0]);
-                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, true, G1, NW>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa, zero4, f_hh, &c.fgh[1]);
-                flow_layer<PERH, FE_CODE, false, false, false, false, PERH, false, G2, NW>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb, zero4, f_hh, &c.fgh[2]);
-                flow_layer<1, FE_ELU, false, false, false, true, PERH, false, GP, NW>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, zero4, f_d0, &c.fd0);
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb);
+                //         PER   epilogue  two    add    pre_in pre_out       rearm  filler    pending
+                flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW, false, FB_E1>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb, pfw, pfx, zero4, f_hh, &c.fgh[0], nullptr);
+                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, true, G1, NW, P, FB_E2>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa, pfw, pfx, zero4, f_hh, &c.fgh[1], PENDING(&c.fgh[0]));
+                flow_layer<PERH, FE_CODE, false, false, false, false, PERH, false, G2, NW, P>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb, pfw, pfx, zero4, f_hh, &c.fgh[2], PENDING(&c.fgh[1]));
+                flow_layer<1, FE_ELU, false, false, false, true, PERH, false, GP, NW, P, FB_Q1>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, pfw, pfx, zero4, f_d0, &c.fd0, PENDING(&c.fgh[2]));
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW, P>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb, pfw, pfx, zero4, f_d0, nullptr, PENDING(&c.fd0));
                 if (FILL) {
                     FlowLin d0 = L(a.dec0z);                   // dec.0: only the phi_z half is left; the bias travels with dec0h
                     d0.bias = a.dec0h.bias;
-                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, d0, wa);
-                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G0, NW>(c, 7, d0, FB_Q3, d0, 0, hb, hb, FB_D1, wa, L(a.dec1), wb, c.fd0, f_iz, &c.fgi[0]);
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, d0, wa, pfw, pfx);
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G0, NW, false, FB_D1>(c, 7, d0, FB_Q3, d0, 0, hb, hb, FB_D1, wa, L(a.dec1), wb, pfw, pfx, c.fd0, f_iz, &c.fgi[0], nullptr);
                 } else {
-                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa);
-                    flow_layer<PERH, FE_ELU, true, false, true, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb);
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa, pfw, pfx);
+                    flow_layer<PERH, FE_ELU, true, false, true, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb, pfw, pfx);
                 }
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_iz, &c.fgi[1]);
-                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_iz, &c.fgi[2]);
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G1, NW, P, FB_D2>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, pfw, pfx, zero4, f_iz, &c.fgi[1], PENDING(&c.fgi[0]));
+                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW, P, FB_D3>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, pfw, pfx, zero4, f_iz, &c.fgi[2], PENDING(&c.fgi[1]));
+                flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW, P>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb, pfw, pfx, zero4, f_iz, nullptr, PENDING(&c.fgi[2]));
             } else {
-                flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, zero4, f_hh, &c.fgh[0]);
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, true, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, zero4, f_hh, &c.fgh[1]);
-                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, zero4, f_hh, &c.fgh[2]);
+                flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW, false, FB_D1>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, pfw, pfx, zero4, f_hh, &c.fgh[0], nullptr);
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, true, G1, NW, P, FB_D2>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, pfw, pfx, zero4, f_hh, &c.fgh[1], PENDING(&c.fgh[0]));
+                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW, P, FB_D3>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, pfw, pfx, zero4, f_hh, &c.fgh[2], PENDING(&c.fgh[1]));
+                flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW, P>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb, pfw, pfx, zero4, f_hh, nullptr, PENDING(&c.fgh[2]));
             }
-            flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb);
-            flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa);
-            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb);
-            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, -2, NW>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa);
+#undef PENDING
+            flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa, pfw, pfx);
+            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb, pfw, pfx);
+            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, -2, NW>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa, pfw, pfx);
             flow_gru<PERH, ENCODE, PERH, FILL, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa);
         } else {
             // the same program on interleaved chains (no filler quanta): wide single-segment layers pipeline their chains
@@ -720,11 +893,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                 flow_layer_chains<PERH, FE_ELU, true, true, true, PERH, false, NW>(c, 1, L(a.enc0h), FB_H, hb, hb, FB_E1, wa, L(a.enc1), wb, mt0, nch, T);
                 flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, true, NW>(c, 2, L(a.enc1), FB_E1, hb, hb, FB_E2, wb, L(a.enc1), wa, mt0, nch, T);
                 flow_layer_chains<PERH, FE_CODE, false, false, false, PERH, false, NW>(c, 3, L(a.enc2), FB_E2, hb, zb, FB_ZC, wa, L(a.enc2), wb, mt0, nch, T);
-                FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa));
+                FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, pfw, pfx));
                 flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 5, L(a.pz1), FB_Q1, hb, hb, FB_Q2, wa, L(a.pz2), wb, mt0, nch, T);
                 flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 6, L(a.pz2), FB_Q2, hb, hb, FB_Q3, wb, L(a.pz2), wa, mt0, nch, T);
                 // two segments share the weight registers: the first segment's weights are fetched per chain
-                FLOW_EACH_CHAIN(flow_layer<PERH, FE_ELU, true, false, false, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb));
+                FLOW_EACH_CHAIN(flow_layer<PERH, FE_ELU, true, false, false, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb, pfw, pfx));
                 flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 8, L(a.dec1), FB_D1, hb, hb, FB_D2, wb, L(a.dec2), wa, mt0, nch, T);
                 flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.dec2), wb, mt0, nch, T);
             } else {
@@ -733,7 +906,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                 flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.dec2), wb, mt0, nch, T);
             }
             flow_layer_chains<PERH, FE_MEL, false, false, false, PERH, false, NW>(c, 10, L(a.dec3), FB_D3, hb, xb, FB_DN, wa, L(a.dec3), wb, mt0, nch, T);
-            FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa));
+            FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa, pfw, pfx));
             flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 12, L(a.px1), FB_G1, hb, hb, FB_G2, wa, L(a.px2), wb, mt0, nch, T);
             flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 13, L(a.px2), FB_G2, hb, hb, FB_G3, wb, L(a.px2), wa, mt0, nch, T);
             FLOW_EACH_CHAIN(flow_gru<PERH, ENCODE, PERH, false, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa); ++c.gructr);
@@ -756,11 +929,12 @@ int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s) {
 constexpr size_t flow_lds(int nw) { return (size_t)(2 * nw * 256 + nw * 6 * 256) * sizeof(float); }      // 64 KiB with 8 waves
 constexpr size_t FLOW_LDS = flow_lds(8);
 constexpr size_t FLOW_LDS_MULTI = FLOW_LDS + (size_t)8 * 6 * 256 * sizeof(float);      // a second slot of GRU partials
+constexpr size_t FLOW_LDS_FILL = FLOW_LDS + (size_t)8 * 8 * 1024 + 16;       // + the waves' operand stashes (128 KiB in all) + the publish flag
 
 template <int PERH, bool ENC>
 static int flow_attr() {
     BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<PERH, ENC, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS));
-    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<PERH, ENC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS));
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<PERH, ENC, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_FILL));
     return BVC_OK;
 }
 
@@ -793,9 +967,9 @@ __global__ void flow_set_args_kernel(FlowArgs *dst, FlowArgs v) {
 
 template <int PERH>
 static void flow_launch_t(const FlowArgs *d_a, bool encode, bool fill, int grid, hipStream_t s) {
-    if (encode && fill)  hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, true, true>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
+    if (encode && fill)  hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, true, true>), dim3(grid), dim3(512), FLOW_LDS_FILL, s, d_a);
     else if (encode)     hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, true, false>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
-    else if (fill)       hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, false, true>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
+    else if (fill)       hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, false, true>), dim3(grid), dim3(512), FLOW_LDS_FILL, s, d_a);
     else                 hipLaunchKernelGGL((bvrnn_flow_kernel<PERH, false, false>), dim3(grid), dim3(512), FLOW_LDS, s, d_a);
 }
 

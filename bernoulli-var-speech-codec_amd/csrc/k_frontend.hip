@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(FrontendTables t, cons
             const float *w = t.mel_w + t.mel_off[j];
             float acc = 0.0f;
             for (int i = 0; i < ln; ++i) acc = fmaf(w[i], mag[st + i], acc);
-            if (live) mel[f * t.num_mels + j] = logf(fmaxf(acc, 1e-5f));
+            if (live) mel[f * t.num_mels + j] = logf(acc < 1e-5f ? 1e-5f : acc);      // torch.clamp(min=1e-5) keeps a NaN (fmaxf would not)
         }
         // next iteration's first LDS write (bufA) is ordered after this iteration's last read of
         // bufA by the two barriers above; mag/zbuf are rewritten only after further barriers.

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             if (p.var_bit) {
                 const Resolved bt = resolve(p.aux, dsc, mt16, p.tstep);
                 const float bits = bt.p[(long long)m * bt.ld];
-                z = (bits > (float)n) ? z : 0.5f;                    // z*m + 0.5*(1-m)
+                z = (bits > (float)n) ? z : (z != z ? z : 0.5f);     // z*m + 0.5*(1-m): a NaN stays a NaN under the mask too (NaN * 0)
             }
             store_out(y, m, n, z);
             const Resolved y3 = resolve(p.y3, dsc, mt16, p.tstep);

@@ -104,9 +104,15 @@ class _Engine:
     def set_option(self, name, value):
         _abi.check(self.lib.bvc_model_set_option(self.handle, name.encode(), int(value)))
 
+    def get_option(self, name):
+        v = ctypes.c_int32(0)
+        _abi.check(self.lib.bvc_model_get_option(self.handle, name.encode(), ctypes.byref(v)))
+        return int(v.value)
+
     def check_status(self):
         """Synchronises the device and raises if a persistent recurrence kernel of this model ever gave up waiting
-        (its results were then invalid); see bvc_model_status in include/bvcodec.h."""
+        (its results were then invalid); see bvc_model_status in include/bvcodec.h.  (Every compute call also looks at
+        the status word, without synchronising, and raises on the first call after a time-out.)"""
         code = ctypes.c_uint32(0)
         with torch.cuda.device(self.device):
             _abi.check(self.lib.bvc_model_status(self.handle, ctypes.byref(code)))
@@ -116,6 +122,12 @@ class _Engine:
 
     def vocoder_length(self, T):
         return int(self.lib.bvc_vocoder_length(self.handle, T))
+
+
+def _trimmed(total, length):
+    """Samples that ``x[:, :, :length]`` keeps of ``total`` (models.py:238): Python slice semantics, so 0 keeps nothing and a
+    negative length cuts from the end."""
+    return len(range(int(total))[:int(length)])
 
 
 def _prep(t, device):
@@ -133,22 +145,29 @@ class _OnDevice(nn.Module):
         self._device = None
 
     def _apply(self, fn, *a, **k):              # follow .to('cuda:N') / .cuda(); there is no CPU residence
-        probe = fn(torch.empty(0))
+        # probe where a tensor that lives where this module lives would end up: a dtype-only conversion (.float(), .half(),
+        # .to(torch.float32)) leaves the device alone and must not forget the residence
+        here = torch.empty(0, device=self._device) if self._device is not None else torch.empty(0)
+        probe = fn(here)
         if probe.device.type == "cuda":
             self._device = _as_device(probe.device)
-        elif probe.device.type == "cpu":        # .cpu(): no residence of its own; the next call follows its input again
+        elif probe.device.type == "cpu" and here.device.type != "cpu":    # .cpu() / .to('cpu'): the next call follows its input again
             self._device = None
         return super()._apply(fn, *a, **k)
 
+    _SCHEDULES = {"persistent": 0, "layers": 1, "auto": 2}
+
     def set_recurrence(self, schedule):
-        """'persistent' (default): every frame of a call in one kernel launch - fastest for one batch at a time;
-        'layers': one launch per layer replayed from hipGraphs - more throughput when several batches are in flight on
-        several streams.  Applies to the engines created so far and to later ones.  Not while a call is in flight."""
-        if schedule not in ("persistent", "layers"):
-            raise ValueError("schedule must be 'persistent' or 'layers'")
+        """'auto' (default): every frame of a call in one persistent kernel launch while calls come one at a time, one launch
+        per layer (hipGraph replay) while calls issued on several streams overlap - the library watches whether the previous
+        call, issued on another stream, is still running when a new one starts;
+        'persistent' / 'layers': that schedule for every call.  Applies to the engines created so far and to later ones.
+        Not while a call is in flight."""
+        if schedule not in self._SCHEDULES:
+            raise ValueError("schedule must be 'auto', 'persistent' or 'layers'")
         self._recurrence = schedule
         for eng in list(self._engines.values()):
-            eng.set_option("recurrence", 1 if schedule == "layers" else 0)
+            eng.set_option("recurrence", self._SCHEDULES[schedule])
 
     def check_status(self):
         """Device-synchronising health check of the engines this module has created (bvc_model_status)."""
@@ -162,8 +181,8 @@ class _OnDevice(nn.Module):
         dev = _as_device(dev)
         if dev not in self._engines:
             self._engines[dev] = _Engine(self.conf, self._tensors, dev)
-            if getattr(self, "_recurrence", None) == "layers":
-                self._engines[dev].set_option("recurrence", 1)
+            if getattr(self, "_recurrence", None) is not None:
+                self._engines[dev].set_option("recurrence", self._SCHEDULES[self._recurrence])
         return self._engines[dev]
 
 
@@ -291,12 +310,13 @@ class BigVGAN(_OnDevice):
         out_dev = x.device
         mel = _prep(x if _time_major else x.permute(0, 2, 1), eng.device)        # kernels are time-major
         B, T, _ = mel.shape
-        n = min(int(length), eng.vocoder_length(T))
+        n = _trimmed(eng.vocoder_length(T), length)
         wav = torch.empty(B, n, device=eng.device)
-        ws, nws = eng.workspace(B, T)
-        with torch.cuda.device(eng.device):
-            _abi.check(eng.lib.bvc_bigvgan(eng.handle, _abi.ptr(mel), B, T, int(length), float(_scale_div),
-                                           _abi.ptr(wav), ws, nws, eng.stream()))
+        if n:
+            ws, nws = eng.workspace(B, T)
+            with torch.cuda.device(eng.device):
+                _abi.check(eng.lib.bvc_bigvgan(eng.handle, _abi.ptr(mel), B, T, n, float(_scale_div),
+                                               _abi.ptr(wav), ws, nws, eng.stream()))
         return wav.unsqueeze(1).to(out_dev)
 
 
@@ -373,12 +393,13 @@ class BVRNNCodecModel(_OnDevice):
         B, T, Z = codes.shape
         if Z != self.conf["z_dim"]:
             raise RuntimeError(f"codes must have {self.conf['z_dim']} values per frame, got {Z}")
-        n = min(int(length), eng.vocoder_length(T))
+        n = _trimmed(eng.vocoder_length(T), length)       # `[:, :, :length]`, models.py:238
         wav = torch.empty(B, n, device=eng.device)
-        ws, nws = eng.workspace(B, T)
-        with torch.cuda.device(eng.device):
-            _abi.check(eng.lib.bvc_decode(eng.handle, _abi.ptr(codes), B, T, int(length), float(SCALING),
-                                          _abi.ptr(wav), ws, nws, eng.stream()))
+        if n:                                             # (length 0 keeps nothing: an empty (B, 0) tensor like the reference's)
+            ws, nws = eng.workspace(B, T)
+            with torch.cuda.device(eng.device):
+                _abi.check(eng.lib.bvc_decode(eng.handle, _abi.ptr(codes), B, T, n, float(SCALING),
+                                              _abi.ptr(wav), ws, nws, eng.stream()))
         return wav.to(out_dev)
 
     def forward(self, x, bitrate):

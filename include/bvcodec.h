@@ -14,17 +14,22 @@
  *  - the compute entry points (bvc_stft_logmel, bvc_bvrnn_*, bvc_bigvgan, bvc_encode, bvc_decode,
  *    bvc_vocoder_stream_push, bvc_pack/unpack_codes, bvc_resample_poly, bvc_peak_normalize) are
  *    asynchronous on `stream` and use only the caller-provided workspace.  They do not allocate or
- *    synchronise, with these exceptions: the FIRST call per process creates one HIP event, and - only
- *    with BVC_RECURRENCE=layers, the launch-per-layer schedule - the first call per (batch,
- *    workspace) captures and instantiates a hipGraph on a stream of the library's own.  Call once
- *    before capturing these entry points into a graph of your own;
+ *    synchronise, with these exceptions: the first calls per process create two HIP events, and the
+ *    launch-per-layer schedule captures and instantiates a hipGraph on a stream of the library's own on
+ *    the first call per (batch, workspace);
+ *  - capturing into a graph of your own: allowed for every compute entry point.  While `stream` is
+ *    being captured a call records no event and waits on none, and its recurrence takes the
+ *    launch-per-layer kernels, launched directly into your capture (the persistent recurrence kernel is
+ *    never captured: see "recurrence" below); the status word is still read when the call is ISSUED, not
+ *    on replay;
  *  - bvc_model_status, bvc_probe_end, bvc_kprobe_* and the bvc_test_* helpers synchronise the device;
  *  - return value: 0 = BVC_OK, negative = error code; bvc_last_error() gives the text
  *    (thread-local); no C++ exception crosses the boundary;
  *  - one in-flight call per (model, workspace): calls on different streams with different
- *    workspaces may overlap (the recurrence kernels of overlapping calls run one after the other,
- *    everything else concurrently); models are immutable after creation; the library is not
- *    re-entrant on ONE model from several host threads at once.
+ *    workspaces may overlap (persistent recurrence kernels of overlapping calls run one after the
+ *    other, everything else concurrently; with the default "recurrence" = auto overlapping calls take
+ *    the launch-per-layer schedule, whose kernels interleave); models are immutable after creation;
+ *    the library is not re-entrant on ONE model from several host threads at once.
  */
 #ifndef BVCODEC_H
 #define BVCODEC_H
@@ -93,19 +98,34 @@ int  bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t 
 void bvc_model_destroy(bvc_model *m);
 
 /* Run-time options of a model (not thread-safe; set them while no call is in flight).
- *   "recurrence": 0 = the persistent recurrence kernel (default: fastest for one batch of up to 64 utterances at a time),
- *                 1 = one launch per layer, hipGraph-replayed (more throughput when several batches are in flight on
- *                     several streams; the start-up default follows BVC_RECURRENCE=layers).
+ *   "recurrence": how the frame loop of BVRNN.encode / BVRNN.decode (bvrnn.py:186-206, 222-227) is scheduled.
+ *                 0 = one persistent kernel launch per call (fastest for one batch at a time),
+ *                 1 = one launch per layer, hipGraph-replayed (more throughput when batches are in flight on several streams),
+ *                 2 = automatic (default; the start-up default follows BVC_RECURRENCE=persistent|layers|auto): persistent while
+ *                     calls come one at a time; while a call starts before the previous one - issued on ANOTHER stream - has
+ *                     finished, launch per layer, for all streams alike.
+ *                 Whatever the option says, a call takes the launch-per-layer kernels when its stream is being captured
+ *                 into a graph (a persistent launch is serialised against other persistent launches by a host-side ticket,
+ *                 which a replay would skip), when the batch is beyond the persistent kernel's limits, or when the
+ *                 residency census at bvc_model_create found that a full persistent grid is not co-resident on this device.
  *   "vocoder_full_tiles": 1 (default) = the eight-channel generator stage runs on the kernel that packs two output rows into
  *                 one MFMA tile, 0 = on the generic kernel (half of every tile is channel padding).  Same bits either way;
- *                 a validation switch, and process-wide rather than per model. */
+ *                 a validation switch, and process-wide rather than per model.
+ *   "flow_spin_limit" (polls before a wait inside the persistent kernel gives up; default 4,000,000, more than a second),
+ *   "flow_debug_withhold" (1: workgroup 0 of every persistent launch does nothing, so its consumers time out),
+ *   "flow_debug_nofill" (1: the plain layer program without filler quanta): test switches.
+ * bvc_model_get_option reads "recurrence", "flow_resident" (1: the census found a full persistent grid co-resident),
+ * "flow_supported" (1: h_dim / z_dim / num_mels are laid out for the persistent kernel), "compute_units". */
 int bvc_model_set_option(bvc_model *m, const char *name, int32_t value);
+int bvc_model_get_option(const bvc_model *m, const char *name, int32_t *value);
 
-/* The recurrence of BVRNN.encode / BVRNN.decode (bvrnn.py:186-206, 222-227) runs as ONE persistent kernel
- * whose workgroups hand activations to each other; every wait in it is bounded.  If a wait ever timed out
- * (a workgroup that never became resident), the kernel ends with invalid results and records it in the
- * model: this call synchronises the device, returns BVC_ETIMEOUT and the recorded code (frame << 4 | layer)
- * and clears it; BVC_OK and 0 otherwise. */
+/* The persistent recurrence kernel's workgroups hand activations to each other, so all of them must be resident together;
+ * every wait in it is bounded.  If a wait ever times out (a workgroup that never became resident: another process on the
+ * device, a CU mask), the kernel still ends, with invalid results, and stores a code (frame << 4 | layer, top bit set) in a
+ * status word in host-mapped memory.  EVERY compute entry point (bvc_encode, bvc_decode, bvc_bvrnn_*, bvc_bigvgan,
+ * bvc_stft_logmel) reads that word first, without synchronising, and returns BVC_ETIMEOUT - once, clearing it - if an
+ * earlier call of this model timed out.  bvc_model_status synchronises the device first, so it also sees calls still in
+ * flight; it returns BVC_ETIMEOUT and the code, and clears it; BVC_OK and 0 otherwise. */
 int bvc_model_status(const bvc_model *m, uint32_t *code);
 
 /* Frames for L samples: floor(L / hop)  (torch.stft center=False after the reflect pad,
@@ -246,6 +266,12 @@ int bvc_probe_end(double *mean_us, double *min_us, int32_t *n_samples);
  * round/mask), 3-5 phi_z, 6-9 dec, 10-12 phi_x, 13 GRU.  Decode step: 0-3 dec, 4-6 phi_x, 7 GRU. */
 int bvc_kprobe_enable(int32_t on);
 int bvc_kprobe_read(int32_t node_lo, int32_t node_hi, double *mean_us, double *min_us, int32_t *n_samples);
+/* Persistent recurrence only: one wave (workgroup BVC_PROBE_WG, wave BVC_PROBE_WAVE; default 0 / 0) stamps per layer and frame:
+ * 0 layer entered, 1 output published; a library built with -DBVC_FLOW_DIAG=1 also 2 flags seen, 3 products done, 4 reduction
+ * barrier passed, 5 layer left.  Mean / min of (stamp `to` - stamp `from`) over the frames of the LAST call for the layers
+ * [node_lo, node_hi); from = -1 measures from the previous layer's stamp 1. */
+int bvc_kprobe_read_span(int32_t from, int32_t to, int32_t node_lo, int32_t node_hi, double *mean_us, double *min_us,
+                         int32_t *n_samples);
 
 #ifdef __cplusplus
 }

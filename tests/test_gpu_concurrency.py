@@ -22,23 +22,52 @@ def _run(model, xs, L, streams, rounds):
     return outs
 
 
-@pytest.mark.parametrize("recurrence", ["persistent", "layers"])
+@pytest.mark.parametrize("recurrence", ["persistent", "layers", "auto"])
 def test_four_stream_schedule_equals_serial(recurrence):
+    """'auto' (the default) runs the serial calls on the persistent kernel and switches to the launch-per-layer schedule once
+    calls of several streams overlap: the two schedules sum in different orders, so under 'auto' a code bit may differ from
+    the serial run where the probability sits within rounding noise of the tie (and only there); the forced schedules are
+    bit-identical to their own serial runs."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_stats import divergence_stats
     from gpu_common import make_model
     from bvcodec import dist as bdist, synth
     env = {"BVC_RECURRENCE": "layers"} if recurrence == "layers" else None
     model, conf, _, _ = make_model(True, 1024, env=env)
+    if recurrence != "layers":
+        model.set_recurrence(recurrence)
     B, L = 64, int(22050 * 1.2)
     xs = [synth.synthetic_speech(B, L, seed=100 + i, kind="noise" if i % 2 else "speech").to(DEV) for i in range(4)]
-    serial = _run(model, xs, L, [torch.cuda.current_stream(DEV)], 1)
-    streams = bdist.concurrent_stream_sets(4, DEV)[0]           # what bench.py uses
-    assert len({s.cuda_stream for s in streams}) == 4
-    conc = _run(model, xs, L, streams, 3)
-    for k, (codes, wav) in enumerate(conc):
-        ref_codes, ref_wav = serial[k % 4]
-        assert torch.equal(codes, ref_codes), f"codes of call {k} differ under the {len(streams)}-stream schedule"
-        assert torch.equal(wav, ref_wav), f"waveform of call {k} differs under the {len(streams)}-stream schedule"
-    model.check_status()
+    try:
+        serial = _run(model, xs, L, [torch.cuda.current_stream(DEV)], 1)
+        streams = bdist.concurrent_stream_sets(4, DEV)[0]           # what bench.py uses
+        assert len({s.cuda_stream for s in streams}) == 4
+        conc = _run(model, xs, L, streams, 3)
+        nb = int(model.bits_per_frame(3000))
+        for k, (codes, wav) in enumerate(conc):
+            ref_codes, ref_wav = serial[k % 4]
+            if recurrence == "auto" and not torch.equal(codes, ref_codes):
+                mel = model.mel_spectrogram(xs[k % 4])
+                bits = torch.full(mel.shape[:2], float(nb), device=DEV)
+                _, _, prob = model.bvrnn.encode(mel, bits, torch.zeros(1, B, 1024, device=DEV), return_prob=True)
+                st = divergence_stats(codes.cpu(), ref_codes.cpu(), prob.cpu(), nb)
+                assert st["max_first_divergence_margin"] < 1e-5, st
+                continue
+            assert torch.equal(codes, ref_codes), f"codes of call {k} differ under the {len(streams)}-stream schedule"
+            if recurrence == "auto":
+                assert (wav - ref_wav).abs().max().item() < 1e-4
+            else:
+                assert torch.equal(wav, ref_wav), f"waveform of call {k} differs under the {len(streams)}-stream schedule"
+        torch.cuda.synchronize(DEV)
+        model.check_status()
+        if recurrence == "auto":                               # ... and one at a time it is the persistent kernel again: same bits as before
+            again = _run(model, xs, L, [torch.cuda.current_stream(DEV)], 2)
+            for k in range(4, 8):
+                assert torch.equal(again[k][0], serial[k % 4][0]) and torch.equal(again[k][1], serial[k % 4][1])
+    finally:
+        if recurrence != "layers":
+            model.set_recurrence("auto")
 
 
 def test_many_workspaces_on_one_model():
@@ -72,7 +101,7 @@ def test_recurrence_schedule_can_be_switched_at_run_time():
         codes_l = model.encode(x, 3000)
         wav_l = model.decode(codes_p, L)                    # same codes in: the decoders must agree to rounding
     finally:
-        model.set_recurrence("persistent")
+        model.set_recurrence("auto")
     assert (wav_l - wav_p).abs().max().item() < 1e-4
     if not torch.equal(codes_l, codes_p):
         mel = model.mel_spectrogram(x)
@@ -108,7 +137,7 @@ def test_large_batch_on_interleaved_chains_equals_layer_schedule(B, frames):
         codes_l = model.encode(x, 3000)
         mel_l, hT_l = model.bvrnn.decode(codes, h0)
     finally:
-        model.set_recurrence("persistent")
+        model.set_recurrence("auto")
     assert torch.equal(codes, codes_l)
     assert (mel - mel_l).abs().max().item() < 1e-5 and (hT - hT_l).abs().max().item() < 5e-6
     oc = ocodec.OracleCodec(conf, sd1, sd2)

@@ -1,0 +1,226 @@
+"""Parity holes and failure paths of the persistent recurrence (round-2 verdict):
+
+* every template family of the persistent kernel (h_dim 128 / 256 / 512, with and without filler quanta) against the oracle,
+* T = 1, length = 0, NaN / Inf in the waveform (must propagate like the reference's arithmetic, no time-out),
+* a recurrence time-out is reported by the NEXT call (status word in host-mapped memory), the residency census,
+* a caller's hipGraph capture takes the launch-per-layer kernels and replays correctly.
+
+Needs the MI355X: run with ``-m gpu``.  Everything goes through the C ABI (ctypes).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _ties_only(codes, ref_codes, ref_prob, tol=1e-5):
+    """Free-running comparison: per utterance, the FIRST differing frame may only differ where the oracle's own
+    probability sits within `tol` of the rounding tie."""
+    diff = codes != ref_codes
+    for b in range(codes.shape[0]):
+        if diff[b].any():
+            t0 = int(diff[b].any(dim=1).nonzero()[0])
+            bad = diff[b, t0].nonzero().flatten()
+            assert ((ref_prob[b, t0, bad] - 0.5).abs() < tol).all(), (b, t0, ref_prob[b, t0, bad])
+    return int(diff.sum())
+
+
+# --------------------------------------------------------------------------- h_dim families of bvrnn_flow_kernel<PERH, ...>
+@pytest.mark.parametrize("nofill", [0, 1])
+@pytest.mark.parametrize("B", [5, 64])
+@pytest.mark.parametrize("h_dim", [128, 256, 512])
+def test_persistent_kernel_families_vs_oracle(h_dim, B, nofill):
+    """bvrnn.py:186-206 / 222-227 at h_dim 128 / 256 / 512 (bvrnn_flow_kernel<1|2|4, ...>; the reference takes any h_dim from
+    the TOML, bvrnn_codec_model.py:30): codes against oracle.bvrnn.encode, mel^ / h_T against oracle.bvrnn.decode.  nofill:
+    the plain layer program (at h_dim <= 128 its dec.0 has both halves on the one-block-per-wave path)."""
+    from gpu_common import make_model
+    from oracle import bvrnn as obv
+    model, conf, vr, _ = make_model(True, h_dim)
+    eng = model.engine()
+    assert eng.get_option("flow_supported") == 1 and eng.get_option("flow_resident") == 1
+    rng = np.random.default_rng(h_dim + B)
+    T = 24
+    y = torch.from_numpy((-4.0 + 1.6 * rng.standard_normal((B, T, 80))).astype(np.float32))
+    bits = torch.from_numpy(rng.integers(8, 65, size=(B, T)).astype(np.float32))
+    h0 = torch.from_numpy((0.2 * rng.standard_normal((B, h_dim))).astype(np.float32))
+    r = obv.encode(vr, y, bits, h0)
+    try:
+        model.set_recurrence("persistent")
+        eng.set_option("flow_debug_nofill", nofill)
+        codes, all_h, prob = model.bvrnn.encode(y.to(DEV), bits.to(DEV), h0.unsqueeze(0).to(DEV), return_prob=True)
+        n_diff = _ties_only(codes.cpu(), r["codes"], r["prob"])
+        if n_diff == 0:
+            assert (prob.cpu() - r["prob"]).abs().max().item() < 2e-6
+            assert (all_h.cpu() - r["all_h"]).abs().max().item() < 5e-6
+        d = obv.decode(vr, r["codes"], h0)
+        mel, hT = model.bvrnn.decode(r["codes"].to(DEV), h0.unsqueeze(0).to(DEV))
+        assert (mel.cpu() - d["mel"]).abs().max().item() < 5e-5
+        assert (hT[0].cpu() - d["h_last"]).abs().max().item() < 5e-6
+        torch.cuda.synchronize()
+        model.check_status()
+    finally:
+        eng.set_option("flow_debug_nofill", 0)
+        model.set_recurrence("auto")
+
+
+# --------------------------------------------------------------------------- edge shapes
+def test_single_frame_and_zero_length():
+    """T = 1 through every stage (the facade cannot produce it: reflect padding needs L > 512, i.e. two frames) and
+    decode(codes, 0): `[:, :, :0]` keeps nothing (models.py:238)."""
+    from gpu_common import make_model
+    from oracle import bigvgan as obg, bvrnn as obv
+    model, conf, vr, ge = make_model(True, 1024)
+    rng = np.random.default_rng(3)
+    B = 3
+    y = torch.from_numpy((-4.0 + 1.6 * rng.standard_normal((B, 1, 80))).astype(np.float32))
+    bits = torch.full((B, 1), 35.0)
+    h0 = torch.from_numpy((0.2 * rng.standard_normal((B, 1024))).astype(np.float32))
+    r = obv.encode(vr, y, bits, h0)
+    codes, all_h = model.bvrnn.encode(y.to(DEV), bits.to(DEV), h0.unsqueeze(0).to(DEV))
+    _ties_only(codes.cpu(), r["codes"], r["prob"])
+    assert torch.equal(all_h.cpu()[:, 0], h0)                       # all_h[:, 0] is the state BEFORE the frame (bvrnn.py:205)
+    d = obv.decode(vr, r["codes"], h0)
+    mel, hT = model.bvrnn.decode(r["codes"].to(DEV), h0.unsqueeze(0).to(DEV))
+    assert (mel.cpu() - d["mel"]).abs().max().item() < 5e-5 and (hT[0].cpu() - d["h_last"]).abs().max().item() < 5e-6
+    wav = model.vocoder(d["mel"].permute(0, 2, 1).to(DEV), 10 ** 9)
+    ref = obg.forward(ge, conf["vocoder_config"], d["mel"].permute(0, 2, 1), 10 ** 9)
+    assert wav.shape == ref.shape == (B, 1, 256 + 294)
+    assert float((wav.cpu() - ref).pow(2).mean().sqrt()) < 1e-5
+    # the facade's decode on one frame, all lengths of the slice semantics
+    full = model.decode(r["codes"].to(DEV), 10 ** 9)
+    assert full.shape == (B, 550)
+    assert model.decode(r["codes"].to(DEV), 0).shape == (B, 0)
+    assert torch.equal(model.decode(r["codes"].to(DEV), -50), full[:, :-50])
+    assert torch.equal(model.decode(r["codes"].to(DEV), 100), full[:, :100])
+    assert model.vocoder(d["mel"].permute(0, 2, 1).to(DEV), 0).shape == (B, 1, 0)
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_nonfinite_samples_propagate_like_the_reference(bad):
+    """One NaN / Inf sample: the frames whose analysis window covers it, and every later frame of THAT utterance (the state is
+    NaN from then on), are NaN in all 64 positions (z * m + 0.5 * (1 - m) with z = NaN, bvrnn.py:193-194); the frames before it
+    and every other utterance are bit-identical to the clean run; nothing waits for ever."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    model = make_model(True, 1024)[0]
+    B, L = 20, 256 * 30 + 40
+    x = synth.synthetic_speech(B, L, seed=11, kind="speech").to(DEV)
+    clean = model.encode(x, 3000)
+    xb = x.clone()
+    k = 256 * 12 + 7                          # sample k lies in the windows of frames (k - 768) / 256 < t <= (k + 256) / 256
+    xb[4, k] = bad
+    codes = model.encode(xb, 3000)
+    torch.cuda.synchronize()
+    model.check_status()
+    first = (k - 768) // 256 + 1
+    others = [b for b in range(B) if b != 4]
+    assert torch.equal(codes[others], clean[others])
+    assert torch.equal(codes[4, :first], clean[4, :first])
+    if bad != bad:          # NaN poisons every bin of its frames; what an Inf leaves (Inf - Inf, sigmoid(+-Inf)) depends on the order of sums
+        assert torch.isnan(codes[4, first:]).all()
+    else:
+        assert not torch.equal(codes[4, first:first + 4], clean[4, first:first + 4])
+    wav = model.decode(codes, L)
+    torch.cuda.synchronize()
+    model.check_status()
+    assert torch.isfinite(wav[others]).all()
+    if bad != bad:
+        assert torch.isnan(wav[4]).any()
+    assert torch.equal(wav[others], model.decode(clean, L)[others])
+
+
+# --------------------------------------------------------------------------- failure paths of the persistent kernel
+def test_recurrence_timeout_is_reported_by_the_next_call():
+    """A persistent launch one of whose workgroups never publishes: its consumers give up (bounded waits), the kernel ends and
+    the NEXT compute call - without any explicit status query - fails with BVC_ETIMEOUT; the call after that works again."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    model = make_model(True, 1024)[0]
+    eng = model.engine()
+    x = synth.synthetic_speech(8, 256 * 6 + 3, seed=1, kind="speech").to(DEV)
+    good = model.encode(x, 3000)
+    try:
+        model.set_recurrence("persistent")
+        eng.set_option("flow_spin_limit", 2000)
+        eng.set_option("flow_debug_withhold", 1)
+        model.encode(x, 3000)                                  # returns normally: the launch is asynchronous
+        torch.cuda.synchronize()
+        eng.set_option("flow_debug_withhold", 0)
+        eng.set_option("flow_spin_limit", 4000000)
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            model.encode(x, 3000)
+    finally:
+        eng.set_option("flow_debug_withhold", 0)
+        eng.set_option("flow_spin_limit", 4000000)
+        model.set_recurrence("auto")
+    assert torch.equal(model.encode(x, 3000), good)            # the status word was cleared by the report
+    torch.cuda.synchronize()
+    model.check_status()
+
+
+def test_residency_census_guards_the_persistent_schedule():
+    """bvc_model_create counts whether a full persistent grid is co-resident.  With a grid the device cannot hold
+    (BVC_FLOW_CENSUS_OVERSUBSCRIBE) the model stays on the launch-per-layer schedule and still gives the right codes."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    ok = make_model(True, 1024)[0]
+    assert ok.engine().get_option("flow_resident") == 1 and ok.engine().get_option("compute_units") >= 64
+    guarded = make_model(True, 1024, env={"BVC_FLOW_CENSUS_OVERSUBSCRIBE": "1"})[0]
+    assert guarded.engine().get_option("flow_resident") == 0
+    layers = make_model(True, 1024, env={"BVC_RECURRENCE": "layers"})[0]
+    x = synth.synthetic_speech(6, 256 * 10 + 3, seed=2, kind="speech").to(DEV)
+    assert torch.equal(guarded.encode(x, 3000), layers.encode(x, 3000))     # the same kernels: the same bits
+
+
+def test_caller_graph_capture_takes_the_layer_kernels_and_replays():
+    """include/bvcodec.h: a compute call may be captured into the caller's hipGraph; its recurrence then takes the
+    launch-per-layer kernels (no ticket event is recorded or waited inside the capture).  Replays reproduce the eager result
+    of that schedule bit for bit, also on new input written into the captured buffers."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    model = make_model(True, 1024)[0]
+    B, L = 4, 256 * 8 + 40
+    x0 = synth.synthetic_speech(B, L, seed=5, kind="speech").to(DEV)
+    x1 = synth.synthetic_speech(B, L, seed=6, kind="noise").to(DEV)
+    try:
+        model.set_recurrence("layers")
+        ref0 = (model.encode(x0, 3000), None)
+        ref0 = (ref0[0], model.decode(ref0[0], L))
+        ref1c = model.encode(x1, 3000)
+        ref1 = (ref1c, model.decode(ref1c, L))
+    finally:
+        model.set_recurrence("auto")
+    xin = x0.clone()
+    s = torch.cuda.Stream(DEV)
+    s.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(s):
+        model.decode(model.encode(xin, 3000), L)               # warm call on this stream: its workspace exists before the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+        codes = model.encode(xin, 3000)                        # auto schedule: the capture is what selects the layer kernels
+        wav = model.decode(codes, L)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(codes, ref0[0]) and torch.equal(wav, ref0[1])
+    xin.copy_(x1)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(codes, ref1[0]) and torch.equal(wav, ref1[1])
+    assert torch.equal(model.encode(x0, 3000), model.encode(x0, 3000))     # eager calls (persistent again) still work afterwards
+    model.check_status()
+
+
+def test_dtype_only_module_conversion_keeps_the_device():
+    """model.to('cuda:0').float() / .half() must not forget where the module lives (nn.Module._apply probes)."""
+    from gpu_common import make_model
+    model = make_model(True, 64)[0]
+    assert model._device == DEV
+    model.float()
+    assert model._device == DEV
+    model.to(torch.float32)
+    assert model._device == DEV
+    x = torch.zeros(1, 1024)                                   # a CPU input still runs on the module's device
+    assert model.encode(x, 3000).device.type == "cpu"
