@@ -18,9 +18,15 @@ one stream.  Rank 0 prints ONE JSON line: metric/value (audio-seconds coded per 
                   `rocprof_avg_us` / `frac_rocprof` quote the committed rocprofv3 --kernel-trace summary
   parity        - after the timed region: the timed batch's codes against the CPU oracle on sampled
                   utterances (differing bits, margin of the first divergence) and the decoded waveform's RMS error
-  multi_stream  - the same K steps issued round-robin on four HIP streams (4 x 64 utterances in flight)
+  multi_stream  - the same K steps issued round-robin on four HIP streams (4 x 64 utterances in flight); the library's
+                  default recurrence schedule ("auto") switches to the launch-per-layer kernels by itself there
+  gather_ms     - mean duration of the per-step RCCL all-gather (HIP event pair on its stream; 0 without a process group)
+  target_workload / encode_only / streaming - BASELINE configs[3]'s per-GPU shard (64 x 10 s, the north-star target's
+                  utterance length), configs[2] (encode only) and configs[4] (256 streams x 20 ms hops, one hipGraph-
+                  replayed library call per hop: p50 / p99), each timed after the headline with its own parity spot check
   cpu_baseline  - the CPU oracle (oracle/, PyTorch-CPU port of the reference op sequence) timed on the host
-                  cores on a bounded sample of the same workload (rank 0, N=1 only).
+                  cores on a bounded sample of the same workload (rank 0, N=1 only): 3 warm-ups, median of 5, at 8
+                  threads and at all cores.
 
 Other workloads of BASELINE.json: ``--seconds 10`` (the north-star target's utterance length, and with
 ``--bitrate 1500|3000|6000`` one GPU's shard of configs[3]), ``--mode encode`` (configs[2]: front-end + coder only).
@@ -54,8 +60,16 @@ PROBE_NAMES = {1: "bvrnn_flow_kernel<8,encode> / <8,decode> (persistent BVRNN re
                3: "amp_pair_kernel / conv_mfma_kernel (BigVGAN convs)",
                4: "gemm_batched_(lds_)kernel (phi_x / phi_z and the frame-independent halves of enc.0, dec.0 and the GRU input gates, all frames)",
                5: "stft_logmel_kernel", 6: "conv_post_kernel"}
-ROCPROF_SUMMARY = os.path.join(ROOT, "profiles", "r02_kernel_stats_default.csv")
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_per_launch.csv")
+def _latest(name):
+    for tag in ("r03", "r02"):
+        p = os.path.join(ROOT, "profiles", f"{tag}_{name}")
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", f"r03_{name}")
+
+
+ROCPROF_SUMMARY = _latest("kernel_stats_default.csv")
+PMC_SUMMARY = _latest("pmc_per_launch.csv")
 
 
 def flops_per_step(conf, B, T, mode):
@@ -122,11 +136,8 @@ def oracle_leg(conf, model, x, codes, wav, L, bitrate, mode, with_baseline):
     batch; the codes the GPU produced in the timed region are compared bit by bit; the oracle then decodes the GPU's codes
     and the waveform is compared.  cpu_baseline: the oracle timed on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle import codec as ocodec
     from parity_stats import divergence_stats
-    threads = min(16, os.cpu_count() or 1)      # the 1-GPU box's CPU share is 16 cores
-    torch.set_num_threads(threads)
-    oc = ocodec.OracleCodec(conf, synth.bvrnn_state_dict(conf, 1234), synth.generator_state_dict(conf, 1235))
+    oc = get_oracle(conf)
     out = {}
     idx = [0, x.shape[0] // 3, (2 * x.shape[0]) // 3, x.shape[0] - 1]
     xs = x[idx].cpu()
@@ -145,18 +156,194 @@ def oracle_leg(conf, model, x, codes, wav, L, bitrate, mode, with_baseline):
         par["waveform_utterances_checked"] = idx[:2]
     out["parity"] = par
     if with_baseline:
-        b = 32
-        secs = L / FS
-        xb = synth.synthetic_speech(b, L if secs <= 5 else int(FS * 5), seed=0, kind="noise")
-        fn = (lambda t: oc.forward(t, bitrate)) if mode == "codec" else (lambda t: oc.encode(t, bitrate))
-        fn(xb[:1, :FS])                                                  # warm-up (thread pools, mkldnn)
-        t0 = time.time()
-        fn(xb)
-        dt = time.time() - t0
-        out["cpu_baseline"] = {"value": round(b * xb.shape[1] / FS / dt, 3), "unit": "audio-seconds/s", "cores": torch.get_num_threads(),
-                               "kind": "port", "sample": f"{b} x {xb.shape[1] / FS:g} s utterances, "
-                                                         f"{'encode+decode' if mode == 'codec' else 'encode only'} @ {bitrate} bit/s, "
-                                                         f"oracle (PyTorch-CPU eager fp32), {dt:.1f} s wall"}
+        out["cpu_baseline"] = cpu_baseline(oc, L, bitrate, mode)
+    return out
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cores():
+    """Cores this process may really use: the affinity mask, cut to the cgroup's CPU quota where there is one (a GPU box hands
+    one GPU's job a share of the host - 16 cores - while every core stays visible; more threads than that only queue)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return min(n, int(os.environ.get("BVC_BENCH_MAX_THREADS", "16")))
+
+
+def cpu_baseline(oc, L, bitrate, mode):
+    """the oracle on a bounded sample of the workload, 3 warm-ups, median of 5, at 8 threads (the
+    reference was timed at 8 in the build container) and at all the cores this process may use."""
+    b, secs = 16, 2.0
+    xb = synth.synthetic_speech(b, int(FS * secs), seed=0, kind="noise")
+    fn = (lambda t: oc.forward(t, bitrate)) if mode == "codec" else (lambda t: oc.encode(t, bitrate))
+    allc = usable_cores()
+    runs = {}
+    t_all = time.time()
+    for threads in sorted({min(8, allc), allc}):
+        torch.set_num_threads(threads)
+        for _ in range(3):
+            fn(xb[:2])                                                   # warm-ups (thread pools, oneDNN primitives)
+        ts = []
+        for _ in range(5):
+            t0 = time.time()
+            fn(xb)
+            ts.append(time.time() - t0)
+        ts.sort()
+        runs[threads] = {"value": round(b * secs / ts[2], 3), "median_s": round(ts[2], 3), "min_s": round(ts[0], 3), "max_s": round(ts[-1], 3)}
+    best = max(runs, key=lambda k: runs[k]["value"])
+    return {"value": runs[best]["value"], "unit": "audio-seconds/s", "cores": best, "kind": "port",
+            "sample": f"{b} x {secs:g} s utterances, {'encode+decode' if mode == 'codec' else 'encode only'} @ {bitrate:g} bit/s, oracle "
+                      f"(PyTorch-CPU eager fp32), 3 warm-ups + median of 5 per thread count, {time.time() - t_all:.0f} s wall in all",
+            "by_threads": {str(k): v for k, v in runs.items()}, "cpu_model": cpu_model_name(), "cores_usable": allc,
+            "cores_visible": os.cpu_count()}
+
+
+_ORACLE = {}
+_T0 = time.time()
+
+
+def note(msg):
+    """Progress on stderr (stdout carries the one JSON line): a long run must not look hung."""
+    print(f"[bench {time.time() - _T0:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
+
+def get_oracle(conf):
+    if "oc" not in _ORACLE:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle import codec as ocodec
+        torch.set_num_threads(usable_cores())
+        _ORACLE["oc"] = ocodec.OracleCodec(conf, synth.bvrnn_state_dict(conf, 1234), synth.generator_state_dict(conf, 1235))
+    return _ORACLE["oc"]
+
+
+def spot_check(conf, model, x_rows, codes_rows, wav_rows, n_wav, bitrate, frames=None):
+    """Oracle check of a few rows of a leg's output: code bits (free-running; margin of the first divergence, if any) and the
+    waveform of the oracle decoding the GPU's codes.  x_rows (n, L) / codes_rows (n, F, z) / wav_rows (n, >= n_wav) on any device."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity_stats import divergence_stats
+    oc = get_oracle(conf)
+    r = oc.encode(x_rows.cpu(), bitrate, full=True)
+    F = codes_rows.shape[1] if frames is None else frames
+    nb = min(int(model.bits_per_frame(bitrate)) if conf["var_bit"] else conf["z_dim"], conf["z_dim"])
+    st = divergence_stats(codes_rows.cpu()[:, :F], r["codes"][:, :F], r["prob"][:, :F], nb)
+    par = {"code_bits_checked": int(codes_rows.shape[0] * F * nb), "code_bits_differing": st["mismatching_bits_total"],
+           "max_first_divergence_margin": st["max_first_divergence_margin"]}
+    if wav_rows is not None:
+        ref = oc.decode(codes_rows.cpu()[:, :F], n_wav)
+        par["waveform_rms_error"] = float((wav_rows.cpu()[:, :n_wav] - ref).pow(2).mean().sqrt())
+        par["waveform_rms"] = float(ref.pow(2).mean().sqrt())
+    return par
+
+
+def time_steps(fn, n, device):
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(n):
+        last = fn()
+    torch.cuda.synchronize(device)
+    return time.perf_counter() - t0, last
+
+
+def leg_target_workload(conf, model, device, B, bitrate, with_parity, steps=5):
+    """The workload the north-star target is quoted on (10 s utterances; = one GPU's 64 of BASELINE configs[3]'s 512)."""
+    L = int(FS * 10.0)
+    x = synth.synthetic_speech(B, L, seed=1000, kind="noise").to(device)
+
+    def step():
+        codes = model.encode(x, bitrate)
+        return codes, model.decode(codes, L)
+    step()
+    dt, (codes, wav) = time_steps(step, steps, device)
+    model.check_status()
+    out = {"workload": f"BASELINE configs[3] shard: batch {B} x 10 s per GPU @ {bitrate:g} bit/s, full encode -> BigVGAN decode, one batch at a time",
+           "value": round(B * 10.0 * steps / dt, 2), "unit": "audio-seconds/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+           "frames_per_utterance": int(codes.shape[1]), "x_real_time": round(B * 10.0 * steps / dt, 1)}
+    if with_parity:
+        out["parity"] = dict(spot_check(conf, model, x[:1], codes[:1], wav[:1], L, bitrate), utterances_checked=[0])
+    return out
+
+
+def leg_encode_only(conf, model, device, x, bitrate, ref_codes, steps=5):
+    """BASELINE configs[2]: STFT/mel + BVRNN.encode, no vocoder; `recurrence`: the persistent encode launch alone."""
+    B, L = x.shape
+    lib = _abi.load()
+    model.encode(x, bitrate)
+    dt, codes = time_steps(lambda: model.encode(x, bitrate), steps, device)
+    _abi.check(lib.bvc_probe_begin(1, 1, 64))
+    model.encode(x, bitrate)
+    mean, mn, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
+    _abi.check(lib.bvc_probe_end(ctypes.byref(mean), ctypes.byref(mn), ctypes.byref(n)))
+    model.check_status()
+    fl = flops_per_step(conf, B, int(codes.shape[1]), "encode")[1][0]
+    out = {"workload": f"BASELINE configs[2]: batch {B} x {L / FS:g} s, encode only (STFT/mel + BVRNN.encode), one batch at a time",
+           "value": round(B * (L / FS) * steps / dt, 2), "unit": "audio-seconds/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+           "recurrence": {"kernel": "bvrnn_flow_kernel<8,encode>", "launch_us": round(mean.value, 1), "gflop": round(fl / 1e9, 1),
+                          "tflops": round(fl / (mean.value * 1e-6) / 1e12, 2) if mean.value else None,
+                          "frac": round(fl / (mean.value * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if mean.value else None,
+                          "timer": "hipEvent pair on the launch stream"}}
+    if ref_codes is not None:      # the same input as the headline leg, whose codes the oracle checks: must be the same bits
+        out["parity"] = {"codes_identical_to_headline_leg": bool(torch.equal(codes, ref_codes)),
+                         "note": "the headline leg's `parity` block is the oracle check of these codes"}
+    return out
+
+
+def leg_streaming(conf, model, device, bitrate, with_parity, streams=256, hop=441, ticks=300):
+    """BASELINE configs[4]: `streams` concurrent streams, 20 ms hops, one library call per hop (front-end -> encode -> decode ->
+    incremental vocoder), replayed from a hipGraph once warm; host-observed latency per hop (synchronised)."""
+    from bvcodec.streaming import StreamingCodec
+    x = synth.synthetic_speech(streams, hop * ticks, seed=3, kind="noise").to(device)
+    sc = StreamingCodec(model, streams, bitrate, hop=hop)
+    lat, frames = [], 0
+    keep_c, keep_w = [], []
+    for i in range(ticks):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        c, w = sc.push(x[:, i * hop:(i + 1) * hop])
+        torch.cuda.synchronize(device)
+        lat.append(time.perf_counter() - t0)
+        frames += c.shape[1]
+        if with_parity and c.shape[1]:
+            keep_c.append(c[:2].clone())
+            keep_w.append(w[:2].clone())
+    model.check_status()
+    import numpy as np
+    l = np.array(lat[50:]) * 1e3
+    out = {"workload": f"BASELINE configs[4]: {streams} streams x {hop}-sample (20 ms) hops @ {bitrate:g} bit/s, encode + decode per hop, "
+                       "bvc_stream_codec_tick replayed from a hipGraph",
+           "p50_ms": round(float(np.percentile(l, 50)), 3), "p99_ms": round(float(np.percentile(l, 99)), 3), "mean_ms": round(float(l.mean()), 3),
+           "hop_budget_ms": round(1e3 * hop / FS, 2), "ticks": ticks, "ticks_timed": int(l.size), "frames_per_hop": round(frames / ticks, 3),
+           "value": round(streams * (hop / FS) / (float(l.mean()) * 1e-3), 1), "unit": "audio-seconds/s (all streams, at the mean hop latency)"}
+    if with_parity:
+        codes, wav = torch.cat(keep_c, 1), torch.cat(keep_w, 1)
+        F = codes.shape[1]
+        out["parity"] = dict(spot_check(conf, model, x[:2], codes, wav, 256 * F, bitrate, frames=F), streams_checked=[0, 1], frames=F)
+    del sc
     return out
 
 
@@ -178,6 +365,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the target_workload / encode_only / streaming legs")
     a = ap.parse_args()
 
     # RCCL prints a version banner on STDOUT when its communicator is created; this program's stdout is one JSON line, so
@@ -215,10 +403,17 @@ def main():
         codes = model.encode(x, a.bitrate)
         return codes, (model.decode(codes, L) if full else None)
 
+    gather_ev = []                                 # (start, end) HIP events around every gather, on the stream it was issued on
+
     def step(slot=0):
         codes, wav = local_step()
         if gathered is not None:                  # the "final gather" of the north star: one RCCL collective
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             torch.distributed.all_gather_into_tensor(gathered[slot], wav)
+            e1.record()
+            gather_ev.append((e0, e1))
+            bdist.fence_collective(device)        # a persistent launch of ANY stream waits for the collective (it holds CUs while it waits for peers)
         return codes, wav
 
     def run(n, streams, fn=step):
@@ -268,7 +463,9 @@ def main():
     streams = pick_streams(a.streams)
     if a.warmup:
         run(max(a.warmup, len(streams)), streams)
+    gather_ev.clear()
     elapsed_local, (codes, wav) = timed(a.steps, streams)
+    gather_ms = (sum(e0.elapsed_time(e1) for e0, e1 in gather_ev) / len(gather_ev)) if gather_ev else 0.0
     elapsed, rank_ms = elapsed_local, [round(1e3 * elapsed_local / a.steps, 3)]
     if use_pg:
         tl = torch.tensor([elapsed_local], device=device, dtype=torch.float64)
@@ -299,6 +496,7 @@ def main():
                    "gather": "rccl all_gather of decoded waveforms" if gathered is not None else "none",
                    "streams": len(streams)},
         "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
+        "gather_ms": round(gather_ms, 3),          # rank 0's mean all-gather time per step (0: no process group, nothing to gather)
     }
 
     if a.multi_streams > 1 and len(streams) == 1:
@@ -314,16 +512,14 @@ def main():
                 dt = float(tm.item())
             return {"value": round(world * B * a.seconds * a.steps / dt, 2), "ms_per_step": round(1e3 * dt / a.steps, 3)}
 
-        res = multi()                                      # default schedule: the persistent recurrences run one after the other
+        res = multi()        # no schedule switch here: the library's default ("auto") sees the overlapping calls and takes the layer kernels
         model.check_status()
-        model.set_recurrence("layers")                     # throughput schedule: one launch per layer, the chains of the streams interleave
-        res_layers = multi()
-        model.set_recurrence("persistent")
         out["multi_stream"] = dict(res, streams=a.multi_streams,
-                                   note=f"{a.multi_streams} x {B} utterances in flight per GPU, same steps round-robin on {a.multi_streams} HIP streams, default "
-                                        "(persistent) recurrence schedule",
-                                   layers_schedule=dict(res_layers, note="the same with model.set_recurrence('layers') (bvc_model_set_option "
-                                                                         "recurrence=1): one launch per layer, hipGraph-replayed"))
+                                   note=f"{a.multi_streams} x {B} utterances in flight per GPU, same steps round-robin on {a.multi_streams} HIP streams; "
+                                        "recurrence schedule left at the library default (auto: launch per layer while calls of several streams overlap)")
+        for _ in range(3):   # back to one batch at a time: the default returns to the persistent kernel after two calls without company
+            local_step()
+        torch.cuda.synchronize(device)
 
     if rank == 0 and not a.no_roofline:
         lib = _abi.load()
@@ -349,14 +545,14 @@ def main():
                            "unit": "TFLOP/s", "frac": round(r["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
                            "traffic": pmc_traffic_bytes("bvrnn_flow_kernel") if dom == 1 else None,
                            "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass: "
-                                           "profiles/r02_pmc_per_launch.csv); algorithmic: the weights once per frame "
+                                           f"profiles/{os.path.basename(PMC_SUMMARY)}); algorithmic: the weights once per frame "
                                            "(85 / 60 MB encode / decode, served by the 256 MB Infinity Cache) + 0.25 MB per audio-second of I/O",
                            "kernel": r["kernel"], "mean_launch_us": r["mean_us"],
                            "launches_per_step": r["launches_per_step"], "gflop_per_launch": round(fl / launches / 1e9, 1),
                            "timer": r["timer"],
                            "rocprof_avg_us": rp,
                            "frac_rocprof": round(fl / launches / (rp * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if rp else None,
-                           "rocprof_source": "profiles/r02_kernel_stats_default.csv (rocprofv3 --kernel-trace --stats of this command)",
+                           "rocprof_source": f"profiles/{os.path.basename(ROCPROF_SUMMARY)} (rocprofv3 --kernel-trace --stats of this command)",
                            "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32).  One launch runs every layer of every frame; it is "
                                    "bound by the hand-offs between dependent layers (two write-through / L1-bypassing round trips "
                                    "of ~0.85 us per layer) and by the per-CU operand stream, not by the matrix pipe (DESIGN.md 4)"}
@@ -368,12 +564,24 @@ def main():
                                          "frac": round(whole / PEAK_FP32_MFMA_TFLOPS, 4),
                                          "gflop_per_audio_second": round(step_flops / (B * a.seconds) / 1e9, 3)}
         out["kernel_families"] = rows
+    default_workload = full and a.seconds == SECONDS and B == BATCH
+    if rank == 0:
+        note("headline, multi_stream and roofline legs done")
+    if rank == 0 and world == 1 and default_workload and not a.no_extra:
+        with_par = not a.no_parity
+        out["target_workload"] = leg_target_workload(conf, model, device, B, a.bitrate, with_par)
+        note("target_workload done")
+        out["encode_only"] = leg_encode_only(conf, model, device, x, a.bitrate, codes)
+        note("encode_only done")
+        out["streaming"] = leg_streaming(conf, model, device, a.bitrate, with_par)
+        note("streaming done")
     if rank == 0 and not (a.no_parity and (a.no_cpu_baseline or world > 1)):
         leg = oracle_leg(conf, model, x, codes, wav, L, a.bitrate, a.mode, with_baseline=(world == 1 and not a.no_cpu_baseline))
         if not a.no_parity:
             out["parity"] = leg["parity"]
         if "cpu_baseline" in leg:
             out["cpu_baseline"] = leg["cpu_baseline"]
+        note("parity / cpu_baseline done")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_pg:

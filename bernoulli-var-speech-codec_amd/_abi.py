@@ -42,6 +42,7 @@ SIGNATURES = {
     "bvc_model_destroy": (None, [_vp]),
     "bvc_model_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _i32]),
     "bvc_model_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(_i32)]),
+    "bvc_flow_fence": (ctypes.c_int, [_vp]),
     "bvc_model_status": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "bvc_num_frames": (_i64, [_vp, _i64]),
     "bvc_vocoder_length": (_i64, [_vp, _i64]),

@@ -978,6 +978,14 @@ int flow_chains(const bvc_model *m, int B, hipStream_t s) {
     return (company || lc.hold > 0) ? 0 : chains;
 }
 
+// Fences (bvc_flow_fence): work a caller issued on some stream - an RCCL collective that holds compute units while it waits for
+// its peers, say - that must have finished before the next persistent launch starts.  A small ring; a persistent launch
+// waits for every pending entry (later launches wait for that launch through the ticket).
+constexpr int FLOW_FENCES = 8;
+struct FlowFence { hipEvent_t ev = nullptr; bool pending = false; };
+FlowFence g_fence[16][FLOW_FENCES];
+unsigned g_fence_n[16] = {};
+
 int mark_call_end(hipStream_t s) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return BVC_OK; }
@@ -1012,7 +1020,7 @@ int flow_census(bvc_model *m) {
     memset(&a, 0, sizeof(a));
     a.census = ctr;
     a.MT = slots; a.MG = 1; a.NTG = ntg;
-    static const bool over = getenv("BVC_FLOW_CENSUS_OVERSUBSCRIBE") != nullptr;      // tests: a grid the device cannot hold
+    const bool over = getenv("BVC_FLOW_CENSUS_OVERSUBSCRIBE") != nullptr;             // tests: a grid the device cannot hold
     if (over) a.MT = slots + 1;
     a.spin_limit = 200000u;                     // ~50 ms: a workgroup that has to queue behind a resident one shows up as a time-out
     int rc = launch_flow(a, d_args, m->flow_perh, true, true, nullptr);
@@ -1079,6 +1087,8 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, int chains, co
         hipEvent_t &ev = g_flow_ev[dev][g_flow_n[dev] % tickets];        // the launch `tickets` launches ago must have finished
         if (!ev) BVC_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         if (g_flow_n[dev] >= (unsigned long long)tickets) BVC_HIP_TRY(hipStreamWaitEvent(s, ev, 0));
+        for (auto &f : g_fence[dev])
+            if (f.pending) { BVC_HIP_TRY(hipStreamWaitEvent(s, f.ev, 0)); f.pending = false; }
         ProbeScope probe(PK_LINEAR, s);
         static const bool fill = !(getenv("BVC_FLOW_FILL") && getenv("BVC_FLOW_FILL")[0] == '0');
         if ((rc = launch_flow(a, w.flow_args, m->flow_perh, encode, fill && !m->flow_debug_nofill && a.MG == 1, s))) return rc;
@@ -1935,6 +1945,22 @@ int bvc_model_set_option(bvc_model *m, const char *name, int32_t value) {
     }
     set_error("bvc_model_set_option: unknown option '%s'", name);
     return BVC_EINVAL;
+}
+
+int bvc_flow_fence(void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    BVC_HIP_TRY(hipStreamIsCapturing(s, &cs));
+    if (cs != hipStreamCaptureStatusNone) { set_error("bvc_flow_fence: not while the stream is being captured"); return BVC_EINVAL; }
+    int dev = 0;
+    BVC_HIP_TRY(hipGetDevice(&dev));
+    dev &= 15;
+    std::lock_guard<std::mutex> lk(g_flow_mu);
+    FlowFence &f = g_fence[dev][g_fence_n[dev]++ % FLOW_FENCES];
+    if (!f.ev) BVC_HIP_TRY(hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
+    BVC_HIP_TRY(hipEventRecord(f.ev, s));
+    f.pending = true;
+    return BVC_OK;
 }
 
 int bvc_model_get_option(const bvc_model *m, const char *name, int32_t *value) {

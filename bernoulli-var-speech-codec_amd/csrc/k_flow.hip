@@ -31,38 +31,60 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-#ifndef BVC_FILL_ORDER
-#define BVC_FILL_ORDER 0
-#endif
 #ifndef BVC_GRU_ROUNDS_FILL
 #define BVC_GRU_ROUNDS_FILL 4      // rounds in which the GRU layer's remaining weights (phi_x third) pass through the registers
 #endif
-// Experiments (compile-time, see tools/flow_variants.sh):
-//   BVC_FLOW_EARLYW    1: the next layer's weights are requested right behind this layer's operand requests (they then travel
-//                         under the products, the reduction and the epilogue and have landed when the next wait begins)
-//   BVC_FLOW_PREPOLL   1: (pipelined fillers) the first poll of the next layer's flags is requested BEFORE the quantum's weights, so
-//                         that it does not return behind them (a wave's loads return in order)
-//   BVC_FLOW_PARTNER_WAIT 1: the wave that shares wave 0's SIMD (wave 4) starts its quantum's products only once wave 0 has
-//                         issued the publishing store (its MFMAs take issue slots from the epilogue)
-// (Measured and dropped: two or three flag polls in flight per wave - 57.9 / 59.2 against 55.7 ms per step: the polls themselves
-// load the hand-off path.)
-//   BVC_FLOW_DIAG      1: the probing lane also stamps flags-seen / products-done / barrier-passed (tools/flow_probe.py --diag)
+// Compile-time switches (tools/flow_variants.py builds and times variants):
+//   BVC_FLOW_EARLYW       1: the next layer's weights are requested right behind this layer's operand requests instead of in front of
+//                         the reduction barrier (the default place).  Worth 0.6 ms per step while spill reloads sat in the epilogues
+//                         (they wait, in order, for everything in flight); costs 1.4 ms without them: 54.3 against 52.8 ms per step
+//   BVC_FLOW_LATEW        1: ... or behind the reduction barrier (nothing but the quantum's weights in front of it)
+//   BVC_FLOW_STASH        1 (default): a wave keeps the operand blocks its filler quanta multiply (h, phi_z: fetched and verified for the
+//                         layer that consumes them first) in LDS, so a quantum requests its weights only
+//   BVC_FLOW_PARTNER_WAIT 1 (default): the wave that shares wave 0's SIMD (wave 4) starts its quantum's products only once wave 0 has
+//                         issued the publishing store (its MFMAs take issue slots from the epilogue everybody waits for)
+//   BVC_FILL_EARLY        1: a quantum's weights are requested inside the layer's segment too (behind the next layer's weights) instead of
+//                         in front of the reduction barrier
+//   BVC_FLOW_DIAG         1: the probing lane also stamps flags-seen / products-done / barrier-passed (tools/flow_variants.py run --diag)
+// What these are about: a compute unit takes vector-memory requests in order, 64 B per clock (1 KiB per wave-instruction = 16
+// clocks), and a wave that issues a request into a full queue stalls.  Everything requested in front of the reduction barrier
+// therefore holds the barrier - and the publishing store behind it - back: 24 KiB per wave there (next weights, quantum weights,
+// quantum operands) cost every filler layer more than a microsecond (stamps: products -> barrier 1.2-1.8 us, 0.2-0.5 without).
+// Measured and dropped: two or three flag polls in flight per wave (57.9 / 59.2 against 55.7 ms per step: the polls
+// themselves load the hand-off path); quanta requested behind the publishing store and multiplied a layer later, with and without a
+// pre-issued poll of the next layer's flags (shorter layer spans, 43.8 against 45.2 us per encode frame, but wave 0 leaves each layer
+// later: 55.0-55.9 against 54.1 ms per step).
 #ifndef BVC_FLOW_EARLYW
 #define BVC_FLOW_EARLYW 0
 #endif
-#ifndef BVC_FLOW_PREPOLL
-#define BVC_FLOW_PREPOLL 0
+#ifndef BVC_FLOW_LATEW
+#define BVC_FLOW_LATEW 0
+#endif
+#ifndef BVC_FLOW_STASH
+#define BVC_FLOW_STASH 1
 #endif
 #ifndef BVC_FLOW_PARTNER_WAIT
-#define BVC_FLOW_PARTNER_WAIT 0
+#define BVC_FLOW_PARTNER_WAIT 1
+#endif
+#ifndef BVC_FILL_EARLY
+#define BVC_FILL_EARLY 0
+#endif
+//   BVC_GRU_FAST          1: the GRU layer's remaining product, W_ih[:, :H] phi_x(d_t) (24 KiB of weights per wave, the layer
+//                         was bound by that stream), gets half its weights requested a layer early (inside phi_x.4's segment), a quarter
+//                         parked in LDS for the whole launch, and only the last quarter streamed inside the layer (h_dim 1024, filler form).
+//                         Measured without effect (52.76 ms per step either way): with its h and phi_z parts taken out by the quanta the layer
+//                         is bound by the 192 MFMAs its two waves per SIMD issue, not by the weight stream any more.  Off by default.
+#ifndef BVC_GRU_FAST
+#define BVC_GRU_FAST 0
+#endif
+//   BVC_FLOW_EPISPLIT     1: the epilogue of the ELU layers is split over waves 0-3 (wave j sums and activates output j of every lane - a
+//                         quarter of the dependent chain -, wave 0 gathers the four from LDS and publishes); waves 4-7 hold their quantum's
+//                         products back until the store is out.  Same operations per output as the one-wave epilogue.
+#ifndef BVC_FLOW_EPISPLIT
+#define BVC_FLOW_EPISPLIT 0
 #endif
 #ifndef BVC_FLOW_DIAG
 #define BVC_FLOW_DIAG 0
-#endif
-//   BVC_FLOW_STASH     1: a wave keeps the operand blocks the filler quanta multiply (h, phi_z: fetched and verified for the layer that
-//                         consumes them first) in LDS, so a quantum requests its weights only
-#ifndef BVC_FLOW_STASH
-#define BVC_FLOW_STASH (BVC_FILL_ORDER >= 3)
 #endif
 constexpr int AUX_SC1 = 16;
 
@@ -99,16 +121,12 @@ struct FlowSrc { unsigned base, vl; };     // scalar byte offset of this wave's 
 // producer block and poll).  A flag can be visible before the rest of its block: the consumer still verifies what it fetches.
 template <int PER>
 __device__ __forceinline__ FlowSrc flow_wait(const FlowWg &g, unsigned buf, int nbdim, int kb0, bool &give_up, unsigned code,
-                                             unsigned &spins, const unsigned *pre = nullptr) {
+                                             unsigned &spins) {
     FlowSrc s;
     // uniform part of every address in the scalar offset, lane part in one shared VGPR
     s.base = __builtin_amdgcn_readfirstlane(buf + (unsigned)(g.mtile * nbdim + kb0) * 1024u);
     s.vl = (unsigned)g.lane * 16u;
     const unsigned fl = (unsigned)(g.lane < PER ? g.lane : PER - 1) * 1024u + 63u * 16u + 12u;
-    if (pre) {                                             // a poll requested at the end of the previous layer (BVC_FLOW_PREPOLL)
-        const unsigned t = *pre;
-        if (!__any(t == FLOW_POISON)) return s;
-    }
     while (!give_up) {
         const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(g.rs, fl, s.base, AUX_SC1);
         if (!__any(t == FLOW_POISON)) break;
@@ -119,14 +137,6 @@ __device__ __forceinline__ FlowSrc flow_wait(const FlowWg &g, unsigned buf, int 
         }
     }
     return s;
-}
-
-// one poll of the flags of blocks [kb0, kb0 + PER), requested without waiting for it (flow_wait looks at it first)
-template <int PER>
-__device__ __forceinline__ unsigned flow_prepoll(const FlowWg &g, unsigned buf, int nbdim, int kb0) {
-    const unsigned base = __builtin_amdgcn_readfirstlane(buf + (unsigned)(g.mtile * nbdim + kb0) * 1024u);
-    const unsigned fl = (unsigned)(g.lane < PER ? g.lane : PER - 1) * 1024u + 63u * 16u + 12u;
-    return __builtin_amdgcn_raw_buffer_load_b32(g.rs, fl, base, AUX_SC1);
 }
 
 template <int PER>
@@ -155,15 +165,18 @@ struct SegHook {
     const float *nw; int nwnb; bool pre;           // next layer's packed weights, k-blocks per row; request them here?
     unsigned long long *st_flags, *st_done;       // BVC_FLOW_DIAG: where to stamp "flags seen" / "products done" (or null)
     LdsX stash;                                    // BVC_FLOW_STASH: keep the verified operand blocks of this segment there (or null)
-    const unsigned *polled;                        // BVC_FLOW_PREPOLL: a poll of this segment's flags that is already on its way (or null)
+    const float *fw; size_t fblock; int fstride;   // BVC_FILL_EARLY: the layer's filler quantum - weights, first block, blocks between k-blocks (fw null: none)
+    const float *gw; size_t gblock;                // BVC_GRU_FAST: the GRU layer's first GRU_EARLY_BLOCKS weight blocks are requested here (gw null: none)
 };
-__device__ __forceinline__ SegHook no_hook() { return SegHook{nullptr, 0, false, nullptr, nullptr, (LdsX)0, nullptr}; }
+constexpr int GRU_EARLY_BLOCKS = 12;               // rounds 0 and 1 of four: 4 k-blocks x 3 gates (gate-interleaved: consecutive 1 KiB blocks)
+__device__ __forceinline__ SegHook no_hook() { return SegHook{nullptr, 0, false, nullptr, nullptr, (LdsX)0, nullptr, 0, 1, nullptr, 0}; }
 
 // acc += W[ntile rows][segment] . X[segment]   for this wave's share of the segment's k-blocks
-template <int PER, int PERN>
+// GRUPRE / FEARLY: (compile time) the hook carries GRU weights / a filler quantum's weights to request behind the operands.
+template <int PER, int PERN, bool GRUPRE = false, bool FEARLY = false>
 __device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int wnb, int nb, unsigned buf, bool w_ready,
                                             f32x4 (&wv)[PER], f32x4 &acc, bool &give_up, unsigned code, int kb_off,
-                                            const SegHook &hk, f32x4 (&wn)[PERN]) {
+                                            const SegHook &hk, f32x4 (&wn)[PERN], f32x4 (&fwv)[PERN], f32x4 (&gqv)[GRU_EARLY_BLOCKS]) {
     const int kb0 = kb_off + g.wave * PER;
     if (PER == 1 && kb0 >= nb) return;                     // wave-uniform: fewer k-blocks than waves
     if (!w_ready) {
@@ -172,21 +185,30 @@ __device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int
         for (int u = 0; u < PER; ++u) wv[u] = wload(ub, (unsigned)g.lane * 16u, u);
     }
     unsigned spins = 0;
-    const FlowSrc src = flow_wait<PER>(g, buf, nb, kb0, give_up, code, spins, hk.polled);
+    const FlowSrc src = flow_wait<PER>(g, buf, nb, kb0, give_up, code, spins);
     if (BVC_FLOW_DIAG && hk.st_flags) *hk.st_flags = __builtin_amdgcn_s_memrealtime();
     const f32x4 acc_in = acc;
-    bool again, first = true;
-    do {
+    u32x4 xr[PER];
+    flow_issue<PER>(g, src, xr);
+    // behind the operand requests (nothing this layer waits for queues behind them; a wave's loads return in order):
+    if (hk.pre) {                                          // the next layer's weights
+        const GPtr ub = uniform_ptr(hk.nw, ((size_t)g.ntile * hk.nwnb + g.wave * PERN) * g.wmul);
+#pragma unroll
+        for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)g.lane * 16u, u);
+    }
+    if (GRUPRE) {                                          // the first half of the GRU layer's weights
+        const GPtr ug = uniform_ptr(hk.gw, hk.gblock * g.wmul);
+#pragma unroll
+        for (int i = 0; i < GRU_EARLY_BLOCKS; ++i) gqv[i] = wload(ug, (unsigned)g.lane * 16u, i);
+    }
+    if (FEARLY) {                                          // the layer's filler quantum's weights (zero blocks if it has none)
+        const GPtr uf = uniform_ptr(hk.fw, hk.fblock * g.wmul);
+#pragma unroll
+        for (int u = 0; u < PERN; ++u) fwv[u] = hk.fw ? wload(uf, (unsigned)g.lane * 16u, u * hk.fstride) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (;;) {
         // The blocks are multiplied as they arrive (the loads return in order); whether one of them still held the
         // sentinel is only known at the end: then the products are thrown away and everything is fetched again.
-        u32x4 xr[PER];
-        flow_issue<PER>(g, src, xr);
-        if (hk.pre && first) {                             // behind the operand requests: nothing this layer waits for queues behind them
-            const GPtr ub = uniform_ptr(hk.nw, ((size_t)g.ntile * hk.nwnb + g.wave * PERN) * g.wmul);
-#pragma unroll
-            for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)g.lane * 16u, u);
-        }
-        first = false;
         f32x4 a2 = acc_in;
         bool bad = false;
 #pragma unroll
@@ -196,25 +218,27 @@ __device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int
 #pragma unroll
             for (int e = 0; e < 4; ++e) a2 = mfma16(wv[u][e], xv[e], a2);
         }
-        again = __any(bad) && !give_up;
-        if (!again) {
+        if (!(__any(bad) && !give_up)) {
             acc = a2;
             if (BVC_FLOW_STASH && hk.stash) {
 #pragma unroll
                 for (int u = 0; u < PER; ++u) hk.stash[(kb_off / 8 * PER + u) * 64 + g.lane] = xr[u];
             }
-        } else if (++spins > g.spin_limit) {
+            break;
+        }
+        if (++spins > g.spin_limit) {
             give_up = true;
             if (g.lane == 0) flow_report(g.status, code);
         }
-    } while (again);
+        flow_issue<PER>(g, src, xr);
+    }
     if (BVC_FLOW_DIAG && hk.st_done) *hk.st_done = __builtin_amdgcn_s_memrealtime();
 }
 template <int PER>
 __device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int wnb, int nb, unsigned buf, bool w_ready,
                                             f32x4 (&wv)[PER], f32x4 &acc, bool &give_up, unsigned code, int kb_off = 0) {
-    f32x4 none[1];
-    lin_segment<PER, 1>(g, w, wnb, nb, buf, w_ready, wv, acc, give_up, code, kb_off, no_hook(), none);
+    f32x4 none[1], nof[1], nog[GRU_EARLY_BLOCKS];
+    lin_segment<PER, 1>(g, w, wnb, nb, buf, w_ready, wv, acc, give_up, code, kb_off, no_hook(), none, nof, nog);
 }
 
 // One round of a GRU segment: HALF k-blocks x 3 gates of weights (gate-interleaved [n/16][k/16][gate][lane][4]).
@@ -234,6 +258,19 @@ __device__ __forceinline__ void gru_round(const f32x4 (&w3)[HALF][3], const u32x
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int q = 0; q < 3; ++q) acc[q] = mfma16(w3[u][q][e], xv[e], acc[q]);
+    }
+}
+
+// the same round on six consecutive weight blocks [k-block][gate] (BVC_GRU_FAST)
+template <int PER>
+__device__ __forceinline__ void gru_round6(const f32x4 *w6, const u32x4 (&xr)[PER], int h0, f32x4 (&acc)[3]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const f32x4 xv = __builtin_bit_cast(f32x4, xr[h0 + u]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc[q] = mfma16(w6[u * 3 + q][e], xv[e], acc[q]);
     }
 }
 
@@ -333,9 +370,10 @@ struct FlowCtx {
     FlowArgsC a;
     float *red_lin, *red_gru;
     LdsX stash;              // BVC_FLOW_STASH: this wave's operand blocks of the quanta's input
-    unsigned prepoll;        // BVC_FLOW_PREPOLL: result of the poll requested at the end of the previous layer ...
-    bool has_prepoll;        // ... if there is one
+    LdsX gpark;              // BVC_GRU_FAST: this wave's parked quarter of the GRU layer's weights: [6 blocks][lane]
     volatile unsigned __attribute__((address_space(3))) *pubflag;      // BVC_FLOW_PARTNER_WAIT: hop count of wave 0's last publishing store
+    unsigned episeq;         // BVC_FLOW_EPISPLIT: split epilogues so far (pubflag[1] counts the outputs written: 4 per epilogue)
+    bool split;              // BVC_FLOW_EPISPLIT: this kernel splits its ELU epilogues
     unsigned par;            // frame parity
     long long t, fr;         // frame; (utterance, frame) index of this lane's row
     int row;
@@ -410,45 +448,75 @@ __device__ __forceinline__ void flow_publish(const FlowCtx &c, int hopid, const 
     flow_stamp(c, hopid, 1);
 }
 
-// One layer: y = epi( sum_s W_s . x_s + bias [+ addend] ).  PER k-blocks per wave and segment (compile time), one or
-// two segments (the one whose input is produced last comes last), PRE_IN: wv already holds segment 0's weights,
-// PRE_OUT: request `nxt`'s weights (PERN blocks per wave) into wn before the reduction.
-// BVC_FILL_ORDER >= 3 ("pipelined fillers"): a quantum's operands are requested BEHIND the layer's publishing store (nothing but
-// the layer's own operand requests sits in the compute unit's in-order request queue in front of the reduction barrier and the
-// store: 1 KiB per wave-instruction is taken at 64 B per clock, so 24 KiB per wave in front of the barrier hold every wave - and
-// the store - back by more than a microsecond) and MULTIPLIED a layer later, behind that layer's reduction barrier, in the shadow
-// of its epilogue and hand-off.  The operands wait in the pend registers (PEND: this layer multiplies the quantum the previous
-// one requested).  3: a second workgroup barrier keeps the other waves' requests behind wave 0's store; 4: no second barrier.
-// NSRC: (BVC_FLOW_PREPOLL) the buffer the NEXT layer waits for first, if it is an h_dim-wide one (else -1).
-template <int PER, int EPI, bool TWO, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H = false, int FGATE = -2, int NW = 8,
-          bool PEND = false, int NSRC = -1>
-__device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin l0, int src0, const FlowLin l1, int src1,
-                                           int nb, int ntiles, int out, f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN],
-                                           f32x4 (&pw)[PERN], u32x4 (&px)[PERN],
-                                           const f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, const FlowFill fill = FlowFill{nullptr, 0, 0, 0u},
-                                           f32x4 *facc = nullptr, f32x4 *pacc = nullptr) {
+// BVC_FLOW_EPISPLIT, ELU layers: waves 0-3 each reduce and activate ONE of the four outputs of every lane (r2: [lane][4] in LDS),
+// count themselves in; wave 0 then gathers and publishes like flow_publish.  b1 / a1: this wave's bias / addend element.
+template <bool ADD, bool REARM_H, int NW>
+__device__ __forceinline__ void flow_publish_split(FlowCtx &c, int hopid, const float *r, float *r2, unsigned ytile, int out, float b1, float a1) {
     const FlowWg &g = c.g;
     const auto &a = *c.a;
-    constexpr bool PIPE = BVC_FILL_ORDER >= 3;
+    const int lane = g.lane, j = g.wave;
+    volatile unsigned __attribute__((address_space(3))) *ctr = c.pubflag + 1;
+    __builtin_amdgcn_s_setprio(3);
+    float v = r[lane * 4 + j];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) v += r[(w * 64 + lane) * 4 + j];
+    v += b1;
+    if (ADD) v += a1;
+    r2[lane * 4 + j] = elu1(v);
+    __hip_atomic_fetch_add((unsigned __attribute__((address_space(3))) *)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (j == 0) {
+        const unsigned target = 4u * c.episeq;             // (episeq was advanced for this epilogue already)
+        for (int i = 0; i < (1 << 20) && (int)(*ctr - target) < 0; ++i) {}
+        const f32x4 o = *reinterpret_cast<const f32x4 *>(r2 + lane * 4);
+        unsigned pv = FLOW_POISON;
+        asm volatile("" : "+v"(pv));
+        const u32x4 poison4 = {pv, pv, pv, pv};
+        const unsigned ob = (unsigned)(out * 2) * a.slot_bytes;
+        __builtin_amdgcn_raw_buffer_store_b128(publishable(o, c.rowok), g.rs, ob + c.par * a.slot_bytes + ytile, 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, ob + (c.par ^ 1u) * a.slot_bytes + ytile, 0, AUX_SC1);
+        if (REARM_H) __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, (unsigned)(FB_H * 2 + (c.par ^ 1u)) * a.slot_bytes + ytile, 0, AUX_SC1);
+        flow_stamp(c, hopid, 1);
+    }
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// One layer: y = epi( sum_s W_s . x_s + bias [+ addend] ).  PER k-blocks per wave and segment (compile time), one or
+// two segments (the one whose input is produced last comes last), PRE_IN: wv already holds segment 0's weights,
+// PRE_OUT: request `nxt`'s weights (PERN blocks per wave) into wn (inside the last segment, or before the reduction).
+// FGATE != -2: a filler quantum rides on this layer - its weights are requested in front of the reduction barrier (or inside the
+// segment: BVC_FILL_EARLY) and multiplied behind the barrier, in the shadow of the epilogue and the hand-off.
+// GRUPRE: (BVC_GRU_FAST) this is the layer in front of the GRU layer - the first half of the GRU's weights is requested inside its segment (gq).
+template <int PER, int EPI, bool TWO, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H = false, int FGATE = -2, int NW = 8, bool GRUPRE = false>
+__device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin l0, int src0, const FlowLin l1, int src1,
+                                           int nb, int ntiles, int out, f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN],
+                                           f32x4 (&gq)[GRU_EARLY_BLOCKS],
+                                           const f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, const FlowFill fill = FlowFill{nullptr, 0, 0, 0u},
+                                           f32x4 *facc = nullptr) {
+    const FlowWg &g = c.g;
+    const auto &a = *c.a;
     f32x4 fw[PERN];
     u32x4 fx[PERN];
-    const FlowFill pfill = {nullptr, 0, a.hb, 0u};         // (every quantum has h_dim inputs and outputs)
     if (g.ntile >= ntiles) {                               // uniform per workgroup (layers narrower than h_dim)
         if (PRE_OUT && c.pre_now) {
 #pragma unroll
             for (int u = 0; u < PERN; ++u) wn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};      // defined on every path: no value lives across the layer
         }
-        c.has_prepoll = false;                             // (a poll requested for this layer's input: not this workgroup's business)
-        if (PIPE) {
-            if (PEND) fill_multiply<PERN, 0>(g, pfill, pw, px, *pacc, c.stash);
-            if (FGATE != -2) fill_issue<PERN, FGATE>(g, fill, pw, px);
-        } else if (FGATE != -2) {                          // nothing else to do in this layer: the whole quantum right away
+        if (FGATE != -2) {                                 // nothing else to do in this layer: the whole quantum right away
             fill_issue<PERN, FGATE>(g, fill, fw, fx);
             fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc, c.stash);
         }
+        if (BVC_GRU_FAST && GRUPRE) {
+#pragma unroll
+            for (int i = 0; i < GRU_EARLY_BLOCKS; ++i) gq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};     // defined on every path (see wn)
+        }
         return;
     }
-    const int lane = g.lane, wave = g.wave;
+    int lane = g.lane;
+    const int wave = g.wave;
+    // (opaque per layer: what is derived from the lane - tile offsets, feature indices, their float forms - is then recomputed here
+    // instead of being hoisted out of the frame loop for all fourteen layers and SPILLED; a spill reload in an epilogue waits, in
+    // order, for every prefetch the wave has in flight)
+    asm volatile("" : "+v"(lane));
     const unsigned code = (unsigned)((c.t << 4) | (unsigned)hopid) | 0x80000000u;
     const int n0 = g.ntile * 16 + (lane >> 4) * 4;
     const unsigned ytile = (unsigned)((g.mtile * ntiles + g.ntile) * 1024 + lane * 16);
@@ -456,7 +524,15 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
     // ---- epilogue operands of wave 0, requested up front
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, add4 = {0.f, 0.f, 0.f, 0.f}, mean4 = {0.f, 0.f, 0.f, 0.f}, std4 = {1.f, 1.f, 1.f, 1.f};
     float bitsv = 0.0f;
-    if (wave == 0) {
+    constexpr bool SPLITC = BVC_FLOW_EPISPLIT && EPI == FE_ELU && NW == 8;
+    const bool SPLIT = SPLITC && c.split;                  // (filler kernels only: their LDS has the counter words)
+    float b1 = 0.0f, a1 = 0.0f;                            // SPLIT: wave j < 4 takes output j of every lane
+    if (SPLIT) {
+        if (wave < 4) {
+            if (l0.bias) b1 = l0.bias[n0 + wave];
+            if (ADD && c.rowok) a1 = a.part0[c.fr * (ntiles * 16) + n0 + wave];
+        }
+    } else if (wave == 0) {
         if (l0.bias) bias4 = *reinterpret_cast<const f32x4 *>(l0.bias + n0);
         if (ADD && c.rowok) add4 = *reinterpret_cast<const f32x4 *>(a.part0 + c.fr * (ntiles * 16) + n0);
         if (EPI == FE_CODE && a.var_bit && c.rowok) bitsv = a.bits[c.fr];
@@ -466,67 +542,77 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
         }
     }
     f32x4 acc = acc0;
-    // EARLYW: the next layer's weights are requested inside the (last) segment, right behind its operand requests
+    // EARLY: the next layer's weights are requested inside the (last) segment, right behind its operand requests
     constexpr bool EARLY = BVC_FLOW_EARLYW && PRE_OUT && PER > 1;
+    constexpr bool FEARLY = BVC_FILL_EARLY && FGATE != -2 && PER > 1;
     SegHook hk = no_hook();
     if (BVC_FLOW_DIAG) { hk.st_flags = flow_stamp_slot(c, hopid, 2); hk.st_done = flow_stamp_slot(c, hopid, 3); }
     // the layer behind which the first quantum of a product is requested is the one that fetches that product's input
     if (BVC_FLOW_STASH && FGATE == 0) hk.stash = c.stash;
-    if (BVC_FLOW_PREPOLL && PER > 1 && !TWO && c.has_prepoll) hk.polled = &c.prepoll;
-    c.has_prepoll = false;
     if (PER == 1) {                                        // a narrow input (<= 8 k-blocks): one block per wave and pass
         for (int off = 0; off < nb; off += NW)
-            lin_segment<PER, PERN>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, off, hk, wn);
+            lin_segment<PER, PERN>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, off, hk, wn, fw, gq);
         if (TWO)                                           // (h_dim <= 128 without filler quanta: dec.0 of encode has both halves here)
             for (int off = 0; off < nb; off += NW)
-                lin_segment<PER, PERN>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, off, hk, wn);
+                lin_segment<PER, PERN>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, off, hk, wn, fw, gq);
     } else {
         SegHook hl = hk;
         if (EARLY) { hl.nw = nxt.w; hl.nwnb = nxt.wnb; hl.pre = c.pre_now; }
+        constexpr bool GP = BVC_GRU_FAST && GRUPRE;
+        if (GP) { hl.gw = a.w_ihx; hl.gblock = ((size_t)g.ntile * 2 * a.hb + wave * PER) * 3; }
+        if (FEARLY && fill_active<PERN, FGATE>(g, fill)) {
+            static_assert(!FEARLY || BVC_FLOW_STASH, "BVC_FILL_EARLY requests the quantum's weights only: its input must come from the stash");
+            hl.fw = fill.w;
+            hl.fblock = FGATE >= 0 ? ((size_t)g.ntile * fill.wnb + wave * PERN) * 3 + FGATE : (size_t)g.ntile * fill.wnb + wave * PERN;
+            hl.fstride = FGATE >= 0 ? 3 : 1;
+        }
         if (TWO) {
             lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code);
-            lin_segment<PER, PERN>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, 0, hl, wn);
+            lin_segment<PER, PERN, GP, FEARLY>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, 0, hl, wn, fw, gq);
         } else {
-            lin_segment<PER, PERN>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code, 0, hl, wn);
+            lin_segment<PER, PERN, GP, FEARLY>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code, 0, hl, wn, fw, gq);
         }
     }
-    if (PRE_OUT && !EARLY && c.pre_now) {                  // the next layer's weights travel during the reduction and the wait
+    constexpr bool LATE = BVC_FLOW_LATEW && PRE_OUT && !EARLY;
+    if (PRE_OUT && !EARLY && !LATE && c.pre_now) {         // the next layer's weights travel during the reduction and the wait
         const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
     }
-    // BVC_FILL_ORDER: 0 every wave requests its filler operands before the barrier; 1 the publishing wave requests its own behind
-    // its store (a CU's address path takes 64 B per clock: 16 KiB of requests in front of the store everybody waits for); 2 all
-    // waves behind the store.  Measured 56.4 / 56.8 / 59.1 ms per step: behind the store the layer spans get 1 us shorter
-    // (tools/flow_probe.py), but the filler's own fetch is then exposed behind the layer instead of travelling under its reduction.
-    // (Requested earlier still - right behind the layer's own operand requests - the layers get slower: 53.9 vs 49.3 us per frame.)
-    if (!PIPE && FGATE != -2 && (BVC_FILL_ORDER == 0 || (BVC_FILL_ORDER == 1 && wave != 0))) fill_issue<PERN, FGATE>(g, fill, fw, fx);
+    // The quantum's operands are requested in front of the barrier and multiplied behind it.  (Round 2 measured the other orders with
+    // the quantum's input re-fetched from memory: the publishing wave requesting its own behind its store, or every wave behind the
+    // store: 56.8 / 59.1 against 56.4 ms per step - the quantum's own fetch is then exposed behind the layer.)
+    if (FGATE != -2 && !FEARLY) fill_issue<PERN, FGATE>(g, fill, fw, fx);
     float *r = c.red_lin + (c.hopctr & 1u) * (NW * 256);
     ++c.hopctr;
     *reinterpret_cast<f32x4 *>(r + (wave * 64 + lane) * 4) = acc;
     __syncthreads();
     if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 4);
-    if (wave == 0) {
+    if (LATE && wave != 0 && c.pre_now) {                  // (wave 0: behind its store)
+        const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
+#pragma unroll
+        for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
+    }
+    if (SPLIT) {
+        ++c.episeq;
+        if (wave < 4) flow_publish_split<ADD, REARM_H, NW>(c, hopid, r, c.red_lin + (c.hopctr & 1u) * (NW * 256), ytile, out, b1, a1);
+        if (wave == 0 && FGATE != -2) *c.pubflag = c.hopctr;
+        else if (wave >= 4 && FGATE != -2)                 // the quantum's products wait for the store (all four SIMDs carry the epilogue)
+            for (int i = 0; i < 4096 && *c.pubflag != c.hopctr; ++i) __builtin_amdgcn_s_sleep(2);
+    } else if (wave == 0) {
         flow_publish<EPI, ADD, REARM_H, NW>(c, hopid, r, n0, ytile, ntiles, out, bias4, add4, mean4, std4, bitsv);
-        if (BVC_FLOW_PARTNER_WAIT && NW == 8 && (PEND || (!PIPE && FGATE != -2))) *c.pubflag = c.hopctr;
-    } else if (BVC_FLOW_PARTNER_WAIT && NW == 8 && wave == 4 && (PEND || (!PIPE && FGATE != -2))) {
+        if (BVC_FLOW_PARTNER_WAIT && NW == 8 && FGATE != -2) *c.pubflag = c.hopctr;
+        if (LATE && c.pre_now) {
+            const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
+#pragma unroll
+            for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
+        }
+    } else if (BVC_FLOW_PARTNER_WAIT && NW == 8 && wave == 4 && FGATE != -2) {
         // waves 0 and 4 share a SIMD: this wave's MFMAs would take issue slots from the epilogue everybody is waiting for
+        // (stamps: barrier -> published 0.87 us with the partner multiplying, 0.46 with it waiting, 0.42 in layers without a quantum)
         for (int i = 0; i < 4096 && *c.pubflag != c.hopctr; ++i) __builtin_amdgcn_s_sleep(2);
     }
-    if (PIPE) {
-        if (PEND) fill_multiply<PERN, 0>(g, pfill, pw, px, *pacc, c.stash);      // requested a layer ago: long arrived
-        if (FGATE != -2) {
-            if (BVC_FILL_ORDER == 3) __syncthreads();      // wave 0's store is in the queue: the requests go behind it
-            if (BVC_FLOW_PREPOLL && NSRC >= 0) {           // the next layer's first poll goes in front of the quantum's requests
-                c.prepoll = flow_prepoll<PERN>(g, (unsigned)(NSRC * 2 + c.par) * a.slot_bytes, a.hb, wave * PERN);
-                c.has_prepoll = true;
-            }
-            fill_issue<PERN, FGATE>(g, fill, pw, px);
-        }
-    } else {
-        if (FGATE != -2 && (BVC_FILL_ORDER == 2 || (BVC_FILL_ORDER == 1 && wave == 0))) fill_issue<PERN, FGATE>(g, fill, fw, fx);
-        if (FGATE != -2) fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc, c.stash);
-    }
+    if (FGATE != -2) fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc, c.stash);
     if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 5);
 }
 
@@ -548,7 +634,12 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
         }
         return;
     }
-    const int lane = g.lane, wave = g.wave;
+    int lane = g.lane;
+    const int wave = g.wave;
+    // (opaque per layer: what is derived from the lane - tile offsets, feature indices, their float forms - is then recomputed here
+    // instead of being hoisted out of the frame loop for all fourteen layers and SPILLED; a spill reload in an epilogue waits, in
+    // order, for every prefetch the wave has in flight)
+    asm volatile("" : "+v"(lane));
     const unsigned code = (unsigned)((c.t << 4) | (unsigned)hopid) | 0x80000000u;
     const int n0 = g.ntile * 16 + (lane >> 4) * 4;
     const int kb0 = wave * PER;
@@ -633,7 +724,7 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
 // GRU cell (PyTorch gate order r, z, n; bvrnn.py:206,227): gh = W_hh h, gi = W_ih [phi_x_gen ; phi_z]; in decode the
 // phi_z half of gi (+ b_ih) arrives pre-computed (a.part_gru).  Segments in the order their inputs become ready.
 template <int PER, bool ENCODE, int PERN, bool FILL, int NW = 8>
-__device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const FlowLin nxt, f32x4 (&wn)[PERN]) {
+__device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const FlowLin nxt, f32x4 (&wn)[PERN], f32x4 (&gq)[GRU_EARLY_BLOCKS]) {
     const FlowWg &g = c.g;
     const auto &a = *c.a;
     if (g.ntile >= hb) {
@@ -643,7 +734,12 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         }
         return;
     }
-    const int lane = g.lane, wave = g.wave;
+    int lane = g.lane;
+    const int wave = g.wave;
+    // (opaque per layer: what is derived from the lane - tile offsets, feature indices, their float forms - is then recomputed here
+    // instead of being hoisted out of the frame loop for all fourteen layers and SPILLED; a spill reload in an epilogue waits, in
+    // order, for every prefetch the wave has in flight)
+    asm volatile("" : "+v"(lane));
     const unsigned code = (unsigned)((c.t << 4) | (unsigned)hopid) | 0x80000000u;
     const int n0 = g.ntile * 16 + (lane >> 4) * 4;
     const unsigned ytile = (unsigned)((g.mtile * hb + g.ntile) * 1024 + lane * 16);
@@ -659,7 +755,29 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
     // h(t) and (encode) phi_z(z_t) are complete and were verified by this very wave earlier in the frame: their blocks are
     // requested at once and multiplied while phi_x(d_t), the input produced last, is still on its way
     // The weights stream through two register sets: the request for round i+1 is issued before round i is multiplied.
-    if (!(PER == 1 && wave >= hb)) {                       // (wave-uniform) a wave without a k-block of its own contributes zeros
+    if constexpr (FILL && PER == 8 && BVC_GRU_FAST) {
+        // Four rounds of two k-blocks x three gates, in k order (the same sums as the generic form below).  Rounds 0 and 1 were requested
+        // a layer ago (gq), round 2 has been in LDS since the launch began, round 3 is requested into the registers round 0 leaves.
+        const unsigned l16 = (unsigned)lane * 16u;
+        const GPtr ux = uniform_ptr(a.w_ihx, ((size_t)g.ntile * 2 * hb + wave * PER) * 3 * g.wmul);
+        u32x4 xa[PER];
+        gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * a.slot_bytes, hb, xa, c.give_up, code);
+        if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 2);        // (here: flags seen AND operands fetched)
+        // (scheduling fences: hoisting the later rounds' loads above the earlier rounds' products would need registers that are not there)
+        gru_round6<PER>(gq, xa, 0, gi);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gq[i] = wload(ux, l16, 18 + i);                       // round 3: k-blocks 6, 7
+        __builtin_amdgcn_sched_barrier(0);
+        gru_round6<PER>(gq + 6, xa, 2, gi);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gq[6 + i] = __builtin_bit_cast(f32x4, c.gpark[i * 64 + lane]);    // round 2: k-blocks 4, 5
+        __builtin_amdgcn_sched_barrier(0);
+        gru_round6<PER>(gq + 6, xa, 4, gi);
+        gru_round6<PER>(gq, xa, 6, gi);
+        __builtin_amdgcn_sched_barrier(0);
+    } else if (!(PER == 1 && wave >= hb)) {                // (wave-uniform) a wave without a k-block of its own contributes zeros
         constexpr int HALF = FILL ? (PER >= BVC_GRU_ROUNDS_FILL ? PER / BVC_GRU_ROUNDS_FILL : 1) : (PER >= 4 ? PER / 4 : 1);       // k-blocks per round
         constexpr int RPS = PER / HALF;                    // rounds per segment
         constexpr int NSEG = FILL ? 1 : (ENCODE ? 3 : 2);  // FILL: the h and phi_z products were accumulated earlier in the frame
@@ -689,52 +807,57 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
             else                        gru_round<PER, HALF>(wr[i & 1], xa, h0, gi);
         }
     }
-    // epilogue operands of wave 0: requested now, they arrive while the other waves reach the barrier
-    f32x4 bi[3], bh[3], pg[3];
-    u32x4 hprev = {0u, 0u, 0u, 0u};
-    if (wave == 0) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            bi[q] = ENCODE ? *reinterpret_cast<const f32x4 *>(a.b_ih + q * H + n0) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            bh[q] = *reinterpret_cast<const f32x4 *>(a.b_hh + q * H + n0);
-            pg[q] = (!ENCODE && c.rowok) ? *reinterpret_cast<const f32x4 *>(a.part_gru + c.fr * 3 * H + q * H + n0)
-                                         : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        // this workgroup's own block of h(t): written by itself a frame ago (or the initial state)
-        hprev = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, hbuf + c.par * a.slot_bytes + ytile, 0, AUX_SC1));
+    if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 3);
+    // The cell's epilogue is spread over the waves (one wave doing all of it - 48 partial tiles to sum, two sigmoids and a tanh for
+    // each of its four outputs per lane - took 1.5 us with seven waves idle): wave k < 6 sums quantity k (gi_r, gi_z, gi_n, gh_r,
+    // gh_z, gh_n) over the eight waves and adds its bias, wave j < 4 then evaluates the cell for output j of every lane, wave 0
+    // gathers the four and publishes.  Same operations in the same order per output as the one-wave form.
+    // Their operands are requested now: they arrive while the other waves reach the barrier.
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, p4 = {0.f, 0.f, 0.f, 0.f};
+    float hp = 0.0f;
+    if (wave < 3) {
+        if (ENCODE) b4 = *reinterpret_cast<const f32x4 *>(a.b_ih + wave * H + n0);
+        if (!ENCODE && c.rowok) p4 = *reinterpret_cast<const f32x4 *>(a.part_gru + c.fr * 3 * H + wave * H + n0);
+    } else if (wave < 6) {
+        b4 = *reinterpret_cast<const f32x4 *>(a.b_hh + (wave - 3) * H + n0);
     }
+    // this workgroup's own block of h(t): written by itself a frame ago (or the initial state); wave j takes element j of each lane
+    if (wave < 4) hp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g.rs, hbuf + c.par * a.slot_bytes + ytile + (unsigned)wave * 4u, 0, AUX_SC1));
     if (c.pre_now) {   // the first layer of the next frame (after the last frame a harmless extra request: no value is carried across)
         const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
     }
     float *red_gru = c.red_gru + (c.gructr & 1u) * (NW * 6 * 256);      // (two slots only when chains are interleaved: MULTI)
+    float *red2 = c.red_lin + (c.hopctr & 1u) * (NW * 256);            // [6][256] sums | [256] outputs: the layer partials' free slot
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         *reinterpret_cast<f32x4 *>(red_gru + ((wave * 6 + q) * 64 + lane) * 4) = gi[q];
         *reinterpret_cast<f32x4 *>(red_gru + ((wave * 6 + 3 + q) * 64 + lane) * 4) = gh[q];
     }
     __syncthreads();
+    if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 4);
+    if (wave < 6) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(red_gru + (wave * 64 + lane) * 4);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4 *>(red_gru + ((w * 6 + wave) * 64 + lane) * 4);
+        v += b4;                                           // gi: (sum + b_ih) + the pre-computed phi_z part; gh: sum + b_hh
+        if (wave < 3) v += p4;
+        *reinterpret_cast<f32x4 *>(red2 + (wave * 64 + lane) * 4) = v;
+    }
+    __syncthreads();
+    if (wave < 4) {
+        float sgm[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sgm[k] = red2[(k * 64 + lane) * 4 + wave];
+        const float rg = sigmoid1(sgm[3] + sgm[0]);
+        const float zg = sigmoid1(sgm[4] + sgm[1]);
+        const float ng = tanhf(sgm[2] + rg * sgm[5]);
+        red2[6 * 256 + lane * 4 + wave] = (hp - ng) * zg + ng;
+    }
+    __syncthreads();
     if (wave == 0) {
-        f32x4 v[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            v[k] = *reinterpret_cast<const f32x4 *>(red_gru + (k * 64 + lane) * 4);
-#pragma unroll
-            for (int w = 1; w < NW; ++w) v[k] += *reinterpret_cast<const f32x4 *>(red_gru + ((w * 6 + k) * 64 + lane) * 4);
-        }
-        const f32x4 hp4 = __builtin_bit_cast(f32x4, hprev);
-        f32x4 hn;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float gi_r = (v[0][j] + bi[0][j]) + pg[0][j], gi_z = (v[1][j] + bi[1][j]) + pg[1][j];
-            const float gi_n = (v[2][j] + bi[2][j]) + pg[2][j];
-            const float gh_r = v[3][j] + bh[0][j], gh_z = v[4][j] + bh[1][j], gh_n = v[5][j] + bh[2][j];
-            const float rg = sigmoid1(gh_r + gi_r);
-            const float zg = sigmoid1(gh_z + gi_z);
-            const float ng = tanhf(gi_n + rg * gh_n);
-            hn[j] = (hp4[j] - ng) * zg + ng;
-        }
+        const f32x4 hn = *reinterpret_cast<const f32x4 *>(red2 + 6 * 256 + lane * 4);
         if (a.all_h && c.rowok && c.t + 1 < a.T) *reinterpret_cast<f32x4 *>(a.all_h + (c.fr + 1) * H + n0) = hn;   // all_h[:, t+1], bvrnn.py:205
         // h(t)'s slot is NOT re-armed here: other workgroups may still be reading h(t) in their own GRU layer.  It is re-armed
         // by the second layer of frame t+1 (REARM_H), whose inputs prove that every workgroup has left frame t.
@@ -775,13 +898,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     FlowCtx c;
     FlowArgsC ap = (FlowArgsC)(unsigned long long)a0;      // device-resident copy of the arguments (flow_set_args_kernel)
     c.a = ap;
+    // LDS: [2][NW][256] layer partials | [NW][6][256] GRU partials (MULTI: two such slots).  Filler kernels: the waves' operand stashes
+    // (NW x 8 KiB) lie over the GRU partials - the stashes are dead from the last quantum (layer 9) to the next frame's first layer,
+    // whose operand, h(t+1), exists only after wave 0 has read the partials -, then the parked GRU weights (NW x 6 KiB), then the flag.
     c.red_lin = lds;
     c.red_gru = lds + 2 * NW * 256;
-    c.stash = (LdsX)(lds + 2 * NW * 256 + NW * 6 * 256) + (tid >> 6) * (PERH * 64);     // (FILL kernels only: FLOW_LDS_FILL)
-    c.pubflag = (volatile unsigned __attribute__((address_space(3))) *)(lds + 2 * NW * 256 + NW * 6 * 256 + NW * 8 * 256);     // (behind the stashes)
-    c.has_prepoll = false;
-    c.prepoll = 0u;
-    if (FILL && BVC_FLOW_PARTNER_WAIT && tid == 0) *c.pubflag = 0xFFFFFFFFu;
+    c.stash = (LdsX)(lds + 2 * NW * 256) + (tid >> 6) * (PERH * 64);
+    c.gpark = (LdsX)(lds + 2 * NW * 256 + NW * 8 * 256) + (tid >> 6) * (6 * 64);
+    c.pubflag = (volatile unsigned __attribute__((address_space(3))) *)(lds + 2 * NW * 256 + NW * 8 * 256 + NW * 6 * 256);
+    c.episeq = 0u;
+    c.split = FILL && !MULTI;
+    if (FILL && tid == 0) { c.pubflag[0] = 0xFFFFFFFFu; c.pubflag[1] = 0u; }
+    if (FILL) __syncthreads();
     c.g.lane = tid & 63;
     c.g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
@@ -824,8 +952,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     const long long T = ap->T;
     const bool hfull = c.g.ntile < hb;                     // this workgroup owns a tile of the h_dim-wide layers
     f32x4 wa[PERH], wb[PERH], w1[1];
-    f32x4 pfw[PERH];                                       // pipelined fillers: operands of the quantum requested behind the previous layer
-    u32x4 pfx[PERH];
+    f32x4 gq[GRU_EARLY_BLOCKS];                            // BVC_GRU_FAST: the GRU layer's early-requested weights (rounds 0, 1)
+    constexpr bool GFAST = FILL && PERH == 8 && BVC_GRU_FAST && !MULTI;
+    if (GFAST && hfull) {                                  // park round 2 (k-blocks 4, 5 x three gates) of this wave's share of W_ih[:, :H]
+        const GPtr ux = uniform_ptr(ap->w_ihx, (((size_t)c.g.ntile * 2 * hb + c.g.wave * PERH) * 3 + 12) * c.g.wmul);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c.gpark[i * 64 + c.g.lane] = __builtin_bit_cast(u32x4, wload(ux, (unsigned)c.g.lane * 16u, i));
+    }
     {
         const FlowLin first = ENCODE ? L(ap->enc0h) : L(ap->dec0h);
         const GPtr ub = uniform_ptr(first.w, hfull ? (size_t)c.g.ntile * first.wnb + c.g.wave * PERH : 0);
@@ -852,39 +985,35 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
         constexpr int G0 = FILL ? 0 : -2, G1 = FILL ? 1 : -2, G2 = FILL ? 2 : -2, GP = FILL ? -1 : -2;
         const FlowFill f_hh = {a.w_hh, hb, hb, hsrc}, f_d0 = {a.dec0h.w, a.dec0h.wnb, hb, hsrc}, f_iz = {a.w_ihz, 2 * hb, hb, zsrc};
         if constexpr (!MULTI) {
-            // pipelined fillers (BVC_FILL_ORDER >= 3): P marks the layers that multiply the quantum requested behind the previous layer
-            constexpr bool P = FILL && BVC_FILL_ORDER >= 3;
-#define PENDING(accp) (P ? accp : nullptr)
             if (ENCODE) {
-                //         PER   epilogue  two    add    pre_in pre_out       rearm  filler    pending
-                flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW, false, FB_E1>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb, pfw, pfx, zero4, f_hh, &c.fgh[0], nullptr);
-                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, true, G1, NW, P, FB_E2>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa, pfw, pfx, zero4, f_hh, &c.fgh[1], PENDING(&c.fgh[0]));
-                flow_layer<PERH, FE_CODE, false, false, false, false, PERH, false, G2, NW, P>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb, pfw, pfx, zero4, f_hh, &c.fgh[2], PENDING(&c.fgh[1]));
-                flow_layer<1, FE_ELU, false, false, false, true, PERH, false, GP, NW, P, FB_Q1>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, pfw, pfx, zero4, f_d0, &c.fd0, PENDING(&c.fgh[2]));
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW, P>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb, pfw, pfx, zero4, f_d0, nullptr, PENDING(&c.fd0));
+                //         PER   epilogue  two    add    pre_in pre_out       rearm  filler
+                flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb, gq, zero4, f_hh, &c.fgh[0]);
+                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, true, G1, NW>(c, 2, L(a.enc1), FB_E1, L(a.enc1), 0, hb, hb, FB_E2, wb, L(a.enc1), wa, gq, zero4, f_hh, &c.fgh[1]);
+                flow_layer<PERH, FE_CODE, false, false, false, false, PERH, false, G2, NW>(c, 3, L(a.enc2), FB_E2, L(a.enc2), 0, hb, zb, FB_ZC, wa, L(a.enc2), wb, gq, zero4, f_hh, &c.fgh[2]);
+                flow_layer<1, FE_ELU, false, false, false, true, PERH, false, GP, NW>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, gq, zero4, f_d0, &c.fd0);
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 5, L(a.pz1), FB_Q1, L(a.pz1), 0, hb, hb, FB_Q2, wa, L(a.pz2), wb, gq);
                 if (FILL) {
                     FlowLin d0 = L(a.dec0z);                   // dec.0: only the phi_z half is left; the bias travels with dec0h
                     d0.bias = a.dec0h.bias;
-                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, d0, wa, pfw, pfx);
-                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G0, NW, false, FB_D1>(c, 7, d0, FB_Q3, d0, 0, hb, hb, FB_D1, wa, L(a.dec1), wb, pfw, pfx, c.fd0, f_iz, &c.fgi[0], nullptr);
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, d0, wa, gq);
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G0, NW>(c, 7, d0, FB_Q3, d0, 0, hb, hb, FB_D1, wa, L(a.dec1), wb, gq, c.fd0, f_iz, &c.fgi[0]);
                 } else {
-                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa, pfw, pfx);
-                    flow_layer<PERH, FE_ELU, true, false, true, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb, pfw, pfx);
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa, gq);
+                    flow_layer<PERH, FE_ELU, true, false, true, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb, gq);
                 }
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G1, NW, P, FB_D2>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, pfw, pfx, zero4, f_iz, &c.fgi[1], PENDING(&c.fgi[0]));
-                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW, P, FB_D3>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, pfw, pfx, zero4, f_iz, &c.fgi[2], PENDING(&c.fgi[1]));
-                flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW, P>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb, pfw, pfx, zero4, f_iz, nullptr, PENDING(&c.fgi[2]));
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, gq, zero4, f_iz, &c.fgi[1]);
+                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, gq, zero4, f_iz, &c.fgi[2]);
+                flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb, gq);
             } else {
-                flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW, false, FB_D1>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, pfw, pfx, zero4, f_hh, &c.fgh[0], nullptr);
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, true, G1, NW, P, FB_D2>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, pfw, pfx, zero4, f_hh, &c.fgh[1], PENDING(&c.fgh[0]));
-                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW, P, FB_D3>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, pfw, pfx, zero4, f_hh, &c.fgh[2], PENDING(&c.fgh[1]));
-                flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW, P>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb, pfw, pfx, zero4, f_hh, nullptr, PENDING(&c.fgh[2]));
+                flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, gq, zero4, f_hh, &c.fgh[0]);
+                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, true, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, gq, zero4, f_hh, &c.fgh[1]);
+                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, gq, zero4, f_hh, &c.fgh[2]);
+                flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb, gq);
             }
-#undef PENDING
-            flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa, pfw, pfx);
-            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb, pfw, pfx);
-            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, -2, NW>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa, pfw, pfx);
-            flow_gru<PERH, ENCODE, PERH, FILL, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa);
+            flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa, gq);
+            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb, gq);
+            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, -2, NW, GFAST>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa, gq);
+            flow_gru<PERH, ENCODE, PERH, FILL, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa, gq);
         } else {
             // the same program on interleaved chains (no filler quanta): wide single-segment layers pipeline their chains
             // (flow_layer_chains), the two narrow-input layers, the two-segment dec.0 of encode and the GRU go chain by chain
@@ -893,11 +1022,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                 flow_layer_chains<PERH, FE_ELU, true, true, true, PERH, false, NW>(c, 1, L(a.enc0h), FB_H, hb, hb, FB_E1, wa, L(a.enc1), wb, mt0, nch, T);
                 flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, true, NW>(c, 2, L(a.enc1), FB_E1, hb, hb, FB_E2, wb, L(a.enc1), wa, mt0, nch, T);
                 flow_layer_chains<PERH, FE_CODE, false, false, false, PERH, false, NW>(c, 3, L(a.enc2), FB_E2, hb, zb, FB_ZC, wa, L(a.enc2), wb, mt0, nch, T);
-                FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, pfw, pfx));
+                FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 4, L(a.pz0), FB_ZC, L(a.pz0), 0, zb, hb, FB_Q1, w1, L(a.pz1), wa, gq));
                 flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 5, L(a.pz1), FB_Q1, hb, hb, FB_Q2, wa, L(a.pz2), wb, mt0, nch, T);
                 flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 6, L(a.pz2), FB_Q2, hb, hb, FB_Q3, wb, L(a.pz2), wa, mt0, nch, T);
                 // two segments share the weight registers: the first segment's weights are fetched per chain
-                FLOW_EACH_CHAIN(flow_layer<PERH, FE_ELU, true, false, false, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb, pfw, pfx));
+                FLOW_EACH_CHAIN(flow_layer<PERH, FE_ELU, true, false, false, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb, gq));
                 flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 8, L(a.dec1), FB_D1, hb, hb, FB_D2, wb, L(a.dec2), wa, mt0, nch, T);
                 flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.dec2), wb, mt0, nch, T);
             } else {
@@ -906,10 +1035,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                 flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.dec2), wb, mt0, nch, T);
             }
             flow_layer_chains<PERH, FE_MEL, false, false, false, PERH, false, NW>(c, 10, L(a.dec3), FB_D3, hb, xb, FB_DN, wa, L(a.dec3), wb, mt0, nch, T);
-            FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa, pfw, pfx));
+            FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa, gq));
             flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 12, L(a.px1), FB_G1, hb, hb, FB_G2, wa, L(a.px2), wb, mt0, nch, T);
             flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 13, L(a.px2), FB_G2, hb, hb, FB_G3, wb, L(a.px2), wa, mt0, nch, T);
-            FLOW_EACH_CHAIN(flow_gru<PERH, ENCODE, PERH, false, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa); ++c.gructr);
+            FLOW_EACH_CHAIN(flow_gru<PERH, ENCODE, PERH, false, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa, gq); ++c.gructr);
         }
     }
 }
@@ -929,7 +1058,7 @@ int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s) {
 constexpr size_t flow_lds(int nw) { return (size_t)(2 * nw * 256 + nw * 6 * 256) * sizeof(float); }      // 64 KiB with 8 waves
 constexpr size_t FLOW_LDS = flow_lds(8);
 constexpr size_t FLOW_LDS_MULTI = FLOW_LDS + (size_t)8 * 6 * 256 * sizeof(float);      // a second slot of GRU partials
-constexpr size_t FLOW_LDS_FILL = FLOW_LDS + (size_t)8 * 8 * 1024 + 16;       // + the waves' operand stashes (128 KiB in all) + the publish flag
+constexpr size_t FLOW_LDS_FILL = (size_t)(2 * 8 * 256 + 8 * 8 * 256 + 8 * 6 * 256) * sizeof(float) + 16;       // partials | stashes (over the GRU partials) | parked GRU weights | flag: 128 KiB
 
 template <int PERH, bool ENC>
 static int flow_attr() {

@@ -34,6 +34,18 @@ def init_from_env():
     return rank, world, device
 
 
+def fence_collective(device=None):
+    """Call right behind a collective issued on the current stream: the next persistent recurrence launch (which needs every
+    compute unit) then waits for it - an RCCL kernel that is still waiting for its peers holds compute units.  A no-op
+    without a GPU; see bvc_flow_fence in include/bvcodec.h."""
+    if not torch.cuda.is_available():
+        return
+    from . import _abi
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        _abi.check(_abi.load().bvc_flow_fence(_abi.current_stream(dev)))
+
+
 def shard_range(total, world, rank):
     """Contiguous split of `total` utterances; the first total % world ranks take one more."""
     base, extra = divmod(total, world)
@@ -51,6 +63,8 @@ def gather_batch(local, total=None, out=None):
         if out is None:
             out = local.new_empty((local.shape[0] * world,) + tuple(local.shape[1:]))
         dist.all_gather_into_tensor(out, local.contiguous())
+        if local.is_cuda:
+            fence_collective(local.device)
         return out
     sizes = [shard_range(total, world, r) for r in range(world)]
     nmax = max(hi - lo for lo, hi in sizes)
@@ -58,6 +72,8 @@ def gather_batch(local, total=None, out=None):
     pad[: local.shape[0]] = local
     buf = local.new_empty((nmax * world,) + tuple(local.shape[1:]))
     dist.all_gather_into_tensor(buf, pad)
+    if local.is_cuda:
+        fence_collective(local.device)
     return torch.cat([buf[r * nmax: r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
 
 

@@ -128,6 +128,13 @@ int bvc_model_get_option(const bvc_model *m, const char *name, int32_t *value);
  * flight; it returns BVC_ETIMEOUT and the code, and clears it; BVC_OK and 0 otherwise. */
 int bvc_model_status(const bvc_model *m, uint32_t *code);
 
+/* A persistent recurrence launch needs every compute unit of the device.  Work of the caller's own that holds compute units
+ * for an unbounded time - above all an RCCL collective, whose kernel waits for its peers - must not be running beside it.
+ * bvc_flow_fence(stream) marks the work issued on `stream` so far: the next persistent launch of this process on the current
+ * device (any model, any stream) starts only after it has finished.  Cheap (one event record); not needed when the
+ * collective and the codec calls share one stream.  bvcodec/dist.py calls it behind every gather. */
+int bvc_flow_fence(void *stream);
+
 /* Frames for L samples: floor(L / hop)  (torch.stft center=False after the reflect pad,
  * meldataset.py:72-85).  Returns < 0 when L <= win - hop (reflect pad impossible). */
 int64_t bvc_num_frames(const bvc_model *m, int64_t L);
