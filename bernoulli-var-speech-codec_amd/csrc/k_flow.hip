@@ -53,7 +53,9 @@ namespace {
 // Measured and dropped: two or three flag polls in flight per wave (57.9 / 59.2 against 55.7 ms per step: the polls
 // themselves load the hand-off path); quanta requested behind the publishing store and multiplied a layer later, with and without a
 // pre-issued poll of the next layer's flags (shorter layer spans, 43.8 against 45.2 us per encode frame, but wave 0 leaves each layer
-// later: 55.0-55.9 against 54.1 ms per step).
+// later: 55.0-55.9 against 54.1 ms per step); the ELU epilogue split over four waves (wave j reduces and activates output j of every
+// lane, wave 0 gathers through LDS and publishes: barrier -> published stays at 0.45 us, 53.8 against 52.8 ms per step - unlike the
+// GRU cell's, which did shrink from 1.5 to 0.8 us that way, the linear layers' epilogue is not bound by its instruction count).
 #ifndef BVC_FLOW_EARLYW
 #define BVC_FLOW_EARLYW 0
 #endif
@@ -76,12 +78,6 @@ namespace {
 //                         is bound by the 192 MFMAs its two waves per SIMD issue, not by the weight stream any more.  Off by default.
 #ifndef BVC_GRU_FAST
 #define BVC_GRU_FAST 0
-#endif
-//   BVC_FLOW_EPISPLIT     1: the epilogue of the ELU layers is split over waves 0-3 (wave j sums and activates output j of every lane - a
-//                         quarter of the dependent chain -, wave 0 gathers the four from LDS and publishes); waves 4-7 hold their quantum's
-//                         products back until the store is out.  Same operations per output as the one-wave epilogue.
-#ifndef BVC_FLOW_EPISPLIT
-#define BVC_FLOW_EPISPLIT 0
 #endif
 #ifndef BVC_FLOW_DIAG
 #define BVC_FLOW_DIAG 0
@@ -369,11 +365,11 @@ struct FlowCtx {
     FlowWg g;
     FlowArgsC a;
     float *red_lin, *red_gru;
+    unsigned sb;             // bytes per flow buffer slot: kept in a register (every layer needs it before its first request; a scalar
+                             // load there is a cache round trip on the critical path)
     LdsX stash;              // BVC_FLOW_STASH: this wave's operand blocks of the quanta's input
     LdsX gpark;              // BVC_GRU_FAST: this wave's parked quarter of the GRU layer's weights: [6 blocks][lane]
     volatile unsigned __attribute__((address_space(3))) *pubflag;      // BVC_FLOW_PARTNER_WAIT: hop count of wave 0's last publishing store
-    unsigned episeq;         // BVC_FLOW_EPISPLIT: split epilogues so far (pubflag[1] counts the outputs written: 4 per epilogue)
-    bool split;              // BVC_FLOW_EPISPLIT: this kernel splits its ELU epilogues
     unsigned par;            // frame parity
     long long t, fr;         // frame; (utterance, frame) index of this lane's row
     int row;
@@ -438,46 +434,14 @@ __device__ __forceinline__ void flow_publish(const FlowCtx &c, int hopid, const 
     unsigned pv = FLOW_POISON;
     asm volatile("" : "+v"(pv));                       // re-materialised here (hoisted out of the frame loop it gets spilled)
     const u32x4 poison4 = {pv, pv, pv, pv};
-    const unsigned ob = (unsigned)(out * 2) * a.slot_bytes;
-    __builtin_amdgcn_raw_buffer_store_b128(publishable(o, c.rowok), g.rs, ob + c.par * a.slot_bytes + ytile, 0, AUX_SC1);
-    __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, ob + (c.par ^ 1u) * a.slot_bytes + ytile, 0, AUX_SC1);
+    const unsigned ob = (unsigned)(out * 2) * c.sb;
+    __builtin_amdgcn_raw_buffer_store_b128(publishable(o, c.rowok), g.rs, ob + c.par * c.sb + ytile, 0, AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, ob + (c.par ^ 1u) * c.sb + ytile, 0, AUX_SC1);
     // The slot that will receive h(t+1) still holds h(t-1).  This layer's input was produced by workgroups that had all
     // consumed h(t), i.e. had all finished frame t-1: nobody reads h(t-1) any more (same tile shape as this layer's).
-    if (REARM_H) __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, (unsigned)(FB_H * 2 + (c.par ^ 1u)) * a.slot_bytes + ytile, 0, AUX_SC1);
+    if (REARM_H) __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, (unsigned)(FB_H * 2 + (c.par ^ 1u)) * c.sb + ytile, 0, AUX_SC1);
     __builtin_amdgcn_s_setprio(0);
     flow_stamp(c, hopid, 1);
-}
-
-// BVC_FLOW_EPISPLIT, ELU layers: waves 0-3 each reduce and activate ONE of the four outputs of every lane (r2: [lane][4] in LDS),
-// count themselves in; wave 0 then gathers and publishes like flow_publish.  b1 / a1: this wave's bias / addend element.
-template <bool ADD, bool REARM_H, int NW>
-__device__ __forceinline__ void flow_publish_split(FlowCtx &c, int hopid, const float *r, float *r2, unsigned ytile, int out, float b1, float a1) {
-    const FlowWg &g = c.g;
-    const auto &a = *c.a;
-    const int lane = g.lane, j = g.wave;
-    volatile unsigned __attribute__((address_space(3))) *ctr = c.pubflag + 1;
-    __builtin_amdgcn_s_setprio(3);
-    float v = r[lane * 4 + j];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) v += r[(w * 64 + lane) * 4 + j];
-    v += b1;
-    if (ADD) v += a1;
-    r2[lane * 4 + j] = elu1(v);
-    __hip_atomic_fetch_add((unsigned __attribute__((address_space(3))) *)ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (j == 0) {
-        const unsigned target = 4u * c.episeq;             // (episeq was advanced for this epilogue already)
-        for (int i = 0; i < (1 << 20) && (int)(*ctr - target) < 0; ++i) {}
-        const f32x4 o = *reinterpret_cast<const f32x4 *>(r2 + lane * 4);
-        unsigned pv = FLOW_POISON;
-        asm volatile("" : "+v"(pv));
-        const u32x4 poison4 = {pv, pv, pv, pv};
-        const unsigned ob = (unsigned)(out * 2) * a.slot_bytes;
-        __builtin_amdgcn_raw_buffer_store_b128(publishable(o, c.rowok), g.rs, ob + c.par * a.slot_bytes + ytile, 0, AUX_SC1);
-        __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, ob + (c.par ^ 1u) * a.slot_bytes + ytile, 0, AUX_SC1);
-        if (REARM_H) __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, (unsigned)(FB_H * 2 + (c.par ^ 1u)) * a.slot_bytes + ytile, 0, AUX_SC1);
-        flow_stamp(c, hopid, 1);
-    }
-    __builtin_amdgcn_s_setprio(0);
 }
 
 // One layer: y = epi( sum_s W_s . x_s + bias [+ addend] ).  PER k-blocks per wave and segment (compile time), one or
@@ -524,15 +488,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
     // ---- epilogue operands of wave 0, requested up front
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, add4 = {0.f, 0.f, 0.f, 0.f}, mean4 = {0.f, 0.f, 0.f, 0.f}, std4 = {1.f, 1.f, 1.f, 1.f};
     float bitsv = 0.0f;
-    constexpr bool SPLITC = BVC_FLOW_EPISPLIT && EPI == FE_ELU && NW == 8;
-    const bool SPLIT = SPLITC && c.split;                  // (filler kernels only: their LDS has the counter words)
-    float b1 = 0.0f, a1 = 0.0f;                            // SPLIT: wave j < 4 takes output j of every lane
-    if (SPLIT) {
-        if (wave < 4) {
-            if (l0.bias) b1 = l0.bias[n0 + wave];
-            if (ADD && c.rowok) a1 = a.part0[c.fr * (ntiles * 16) + n0 + wave];
-        }
-    } else if (wave == 0) {
+    if (wave == 0) {
         if (l0.bias) bias4 = *reinterpret_cast<const f32x4 *>(l0.bias + n0);
         if (ADD && c.rowok) add4 = *reinterpret_cast<const f32x4 *>(a.part0 + c.fr * (ntiles * 16) + n0);
         if (EPI == FE_CODE && a.var_bit && c.rowok) bitsv = a.bits[c.fr];
@@ -551,10 +507,10 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
     if (BVC_FLOW_STASH && FGATE == 0) hk.stash = c.stash;
     if (PER == 1) {                                        // a narrow input (<= 8 k-blocks): one block per wave and pass
         for (int off = 0; off < nb; off += NW)
-            lin_segment<PER, PERN>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, off, hk, wn, fw, gq);
+            lin_segment<PER, PERN>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * c.sb, false, wv, acc, c.give_up, code, off, hk, wn, fw, gq);
         if (TWO)                                           // (h_dim <= 128 without filler quanta: dec.0 of encode has both halves here)
             for (int off = 0; off < nb; off += NW)
-                lin_segment<PER, PERN>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, off, hk, wn, fw, gq);
+                lin_segment<PER, PERN>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * c.sb, false, wv, acc, c.give_up, code, off, hk, wn, fw, gq);
     } else {
         SegHook hl = hk;
         if (EARLY) { hl.nw = nxt.w; hl.nwnb = nxt.wnb; hl.pre = c.pre_now; }
@@ -567,10 +523,10 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
             hl.fstride = FGATE >= 0 ? 3 : 1;
         }
         if (TWO) {
-            lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code);
-            lin_segment<PER, PERN, GP, FEARLY>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * a.slot_bytes, false, wv, acc, c.give_up, code, 0, hl, wn, fw, gq);
+            lin_segment<PER>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * c.sb, PRE_IN, wv, acc, c.give_up, code);
+            lin_segment<PER, PERN, GP, FEARLY>(g, l1.w, l1.wnb, nb, (unsigned)(src1 * 2 + c.par) * c.sb, false, wv, acc, c.give_up, code, 0, hl, wn, fw, gq);
         } else {
-            lin_segment<PER, PERN, GP, FEARLY>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * a.slot_bytes, PRE_IN, wv, acc, c.give_up, code, 0, hl, wn, fw, gq);
+            lin_segment<PER, PERN, GP, FEARLY>(g, l0.w, l0.wnb, nb, (unsigned)(src0 * 2 + c.par) * c.sb, PRE_IN, wv, acc, c.give_up, code, 0, hl, wn, fw, gq);
         }
     }
     constexpr bool LATE = BVC_FLOW_LATEW && PRE_OUT && !EARLY;
@@ -593,13 +549,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
     }
-    if (SPLIT) {
-        ++c.episeq;
-        if (wave < 4) flow_publish_split<ADD, REARM_H, NW>(c, hopid, r, c.red_lin + (c.hopctr & 1u) * (NW * 256), ytile, out, b1, a1);
-        if (wave == 0 && FGATE != -2) *c.pubflag = c.hopctr;
-        else if (wave >= 4 && FGATE != -2)                 // the quantum's products wait for the store (all four SIMDs carry the epilogue)
-            for (int i = 0; i < 4096 && *c.pubflag != c.hopctr; ++i) __builtin_amdgcn_s_sleep(2);
-    } else if (wave == 0) {
+    if (wave == 0) {
         flow_publish<EPI, ADD, REARM_H, NW>(c, hopid, r, n0, ytile, ntiles, out, bias4, add4, mean4, std4, bitsv);
         if (BVC_FLOW_PARTNER_WAIT && NW == 8 && FGATE != -2) *c.pubflag = c.hopctr;
         if (LATE && c.pre_now) {
@@ -643,7 +593,7 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
     const unsigned code = (unsigned)((c.t << 4) | (unsigned)hopid) | 0x80000000u;
     const int n0 = g.ntile * 16 + (lane >> 4) * 4;
     const int kb0 = wave * PER;
-    const unsigned bufb = (unsigned)(src0 * 2 + c.par) * a.slot_bytes;
+    const unsigned bufb = (unsigned)(src0 * 2 + c.par) * c.sb;
     if (!PRE_IN) {
         const GPtr ub = uniform_ptr(l0.w, ((size_t)g.ntile * l0.wnb + kb0) * g.wmul);
 #pragma unroll
@@ -744,7 +694,7 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
     const int n0 = g.ntile * 16 + (lane >> 4) * 4;
     const unsigned ytile = (unsigned)((g.mtile * hb + g.ntile) * 1024 + lane * 16);
     const long long H = (long long)hb * 16;
-    const unsigned hbuf = (unsigned)(FB_H * 2) * a.slot_bytes;
+    const unsigned hbuf = (unsigned)(FB_H * 2) * c.sb;
     flow_stamp(c, hopid, 0);
     f32x4 gi[3], gh[3];
 #pragma unroll
@@ -761,7 +711,7 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         const unsigned l16 = (unsigned)lane * 16u;
         const GPtr ux = uniform_ptr(a.w_ihx, ((size_t)g.ntile * 2 * hb + wave * PER) * 3 * g.wmul);
         u32x4 xa[PER];
-        gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * a.slot_bytes, hb, xa, c.give_up, code);
+        gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * c.sb, hb, xa, c.give_up, code);
         if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 2);        // (here: flags seen AND operands fetched)
         // (scheduling fences: hoisting the later rounds' loads above the earlier rounds' products would need registers that are not there)
         gru_round6<PER>(gq, xa, 0, gi);
@@ -790,8 +740,8 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         u32x4 xa[PER], xb[PER];
         f32x4 wr[2][HALF][3];
         gru_issue_w<HALF>(FILL ? ux : uh, l16, 0, wr[0]);
-        if (!FILL) gru_issue_known<PER>(g, hbuf + c.par * a.slot_bytes, hb, xa);
-        if (!FILL && ENCODE) gru_issue_known<PER>(g, (unsigned)(FB_Q3 * 2 + c.par) * a.slot_bytes, hb, xb);
+        if (!FILL) gru_issue_known<PER>(g, hbuf + c.par * c.sb, hb, xa);
+        if (!FILL && ENCODE) gru_issue_known<PER>(g, (unsigned)(FB_Q3 * 2 + c.par) * c.sb, hb, xb);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int sg = i / RPS, h0 = (i % RPS) * HALF;
@@ -800,7 +750,7 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
                 gru_issue_w<HALF>(FILL ? ux : (sn == 0 ? uh : ((ENCODE && sn == 1) ? uz : ux)), l16, hn0, wr[(i + 1) & 1]);
             }
             if (i == (NSEG - 1) * RPS)                     // the last segment's input, phi_x(d_t): wait, fetch, verify
-                gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * a.slot_bytes, hb, xa, c.give_up, code);
+                gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * c.sb, hb, xa, c.give_up, code);
             if (FILL)                   gru_round<PER, HALF>(wr[i & 1], xa, h0, gi);
             else if (sg == 0)           gru_round<PER, HALF>(wr[i & 1], xa, h0, gh);
             else if (ENCODE && sg == 1) gru_round<PER, HALF>(wr[i & 1], xb, h0, gi);
@@ -822,7 +772,7 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         b4 = *reinterpret_cast<const f32x4 *>(a.b_hh + (wave - 3) * H + n0);
     }
     // this workgroup's own block of h(t): written by itself a frame ago (or the initial state); wave j takes element j of each lane
-    if (wave < 4) hp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g.rs, hbuf + c.par * a.slot_bytes + ytile + (unsigned)wave * 4u, 0, AUX_SC1));
+    if (wave < 4) hp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g.rs, hbuf + c.par * c.sb + ytile + (unsigned)wave * 4u, 0, AUX_SC1));
     if (c.pre_now) {   // the first layer of the next frame (after the last frame a harmless extra request: no value is carried across)
         const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
@@ -861,7 +811,7 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         if (a.all_h && c.rowok && c.t + 1 < a.T) *reinterpret_cast<f32x4 *>(a.all_h + (c.fr + 1) * H + n0) = hn;   // all_h[:, t+1], bvrnn.py:205
         // h(t)'s slot is NOT re-armed here: other workgroups may still be reading h(t) in their own GRU layer.  It is re-armed
         // by the second layer of frame t+1 (REARM_H), whose inputs prove that every workgroup has left frame t.
-        __builtin_amdgcn_raw_buffer_store_b128(publishable(hn, c.rowok), g.rs, hbuf + (c.par ^ 1u) * a.slot_bytes + ytile, 0, AUX_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(publishable(hn, c.rowok), g.rs, hbuf + (c.par ^ 1u) * c.sb + ytile, 0, AUX_SC1);
         flow_stamp(c, hopid, 1);
     }
     // one chain: red_gru is single-buffered, its next writers are a whole step (and many barriers) away; interleaved chains
@@ -906,10 +856,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     c.stash = (LdsX)(lds + 2 * NW * 256) + (tid >> 6) * (PERH * 64);
     c.gpark = (LdsX)(lds + 2 * NW * 256 + NW * 8 * 256) + (tid >> 6) * (6 * 64);
     c.pubflag = (volatile unsigned __attribute__((address_space(3))) *)(lds + 2 * NW * 256 + NW * 8 * 256 + NW * 6 * 256);
-    c.episeq = 0u;
-    c.split = FILL && !MULTI;
-    if (FILL && tid == 0) { c.pubflag[0] = 0xFFFFFFFFu; c.pubflag[1] = 0u; }
-    if (FILL) __syncthreads();
+    if (FILL && tid == 0) c.pubflag[0] = 0xFFFFFFFFu;
     c.g.lane = tid & 63;
     c.g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
@@ -938,6 +885,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     if (ap->dbg_withhold && bid == 0) return;              // tests: a workgroup that never publishes (its consumers time out)
     if (c.g.ntile >= ap->NTG) return;                      // grid is rounded up to a multiple of 8 feature tiles
     c.g.rs = __builtin_amdgcn_make_buffer_rsrc(ap->flow, 0, (int)(FB_COUNT * 2u * ap->slot_bytes), 0x00020000);
+    c.sb = ap->slot_bytes;
     c.g.spin_limit = ap->spin_limit;
     c.g.wmul = ap->dbg_hot_w ? 0 : 1;
     c.g.status = ap->status;
@@ -978,7 +926,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
             for (int q = 0; q < 3; ++q) { c.fgh[q] = zero4; c.fgi[q] = zero4; }
             c.fd0 = zero4;
         }
-        const unsigned hsrc = (unsigned)(FB_H * 2 + c.par) * a.slot_bytes, zsrc = (unsigned)(FB_Q3 * 2 + c.par) * a.slot_bytes;
+        const unsigned hsrc = (unsigned)(FB_H * 2 + c.par) * c.sb, zsrc = (unsigned)(FB_Q3 * 2 + c.par) * c.sb;
         // FILL: behind a layer, while its successors' inputs are still being produced, a wave multiplies one "quantum" of a product
         // whose input has been complete since the start of the frame (h) or since phi_z (encode): the three gates of W_hh h, the
         // h half of dec.0, the three gates of W_ih[:, H:] phi_z.  The GRU layer then only has phi_x(d_t)'s third left.

@@ -43,21 +43,26 @@ struct ConvArgs {
 
 // sin(x)^2 with |error| < 2.5e-7 (checked against float64 up to |x| = 8060: tests/test_gpu_numerics.py; the reduction
 // constants keep their accuracy while k = x*2/pi stays below ~2^17): three-constant Cody-Waite reduction by pi/2 with fma to
-// r in [-pi/4, pi/4], then ONE even minimax polynomial sin(r)^2 = u*P(u), u = r^2 (|P error| < 5e-10), and
-// sin(x)^2 = sin(r)^2 in even quadrants, 1 - sin(r)^2 (= cos(r)^2) in odd ones: the square removes the
-// quadrant sign, so no second polynomial is needed.  16 VALU operations; ocml's sinf is equally accurate
-// but carries a Payne-Hanek path and costs ~4x the instructions, and the generator evaluates 476 of these
-// per output sample on SIMDs whose issue slots it shares with the MFMAs.
+// r in [-pi/4, pi/4], then ONE even minimax polynomial sin(r)^2 = u*P(u), u = r^2 (|P error| < 5e-10).  The square removes
+// the quadrant sign: sin(x)^2 = sin(r)^2 in even quadrants and 1 - sin(r)^2 in odd ones, i.e. 1/2 -+ (1/2 - sin(r)^2) - so
+// h = u*P(u) - 1/2 is computed by the last fma and its sign is flipped for odd quadrants by a multiply with +-1 whose sign bit is
+// the quadrant's parity.  k comes from the round-to-nearest of adding 1.5 * 2^23 (no rint, no conversion: the parity is the sum's
+// lowest mantissa bit).  14 VALU operations per element, 12 of them packable two elements at a time (round 2: 16 + two
+// conversions, two masks and two selects per pair); max |error| 9.7e-8 against 1.1e-7 before (numpy emulation over +-8060).
+// ocml's sinf is equally accurate but carries a Payne-Hanek path and costs ~4x the instructions, and the generator evaluates
+// 476 of these per output sample on SIMDs whose issue slots it shares with the MFMAs.
 __device__ __forceinline__ float sin_squared(float x) {
-    const float k = rintf(x * 0.636619772367581343f);
+    const float t = fmaf(x, 0.636619772367581343f, 12582912.0f);
+    const float k = t - 12582912.0f;
     float r = fmaf(-k, 1.57079625129699707031e+00f, x);
     r = fmaf(-k, 7.54978941586159635335e-08f, r);
     r = fmaf(-k, 5.39030252995776476554e-15f, r);
     const float u = r * r;
     const float p = fmaf(fmaf(fmaf(fmaf(1.345194032182917e-4f, u, -3.1710113398730755e-3f), u, 4.444364085793495e-2f), u,
                               -3.33333283662796e-1f), u, 1.0f);
-    const float s2 = p * u;
-    return (((int)k) & 1) ? 1.0f - s2 : s2;
+    const float h = fmaf(p, u, -0.5f);
+    const float sg = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, t) << 31) | 0x3F800000u);      // -1 in odd quadrants
+    return fmaf(h, sg, 0.5f);
 }
 
 // SnakeBeta (activations.py:107-120): x + 1/(exp(beta)+1e-9) * sin(x*exp(alpha))^2
@@ -72,9 +77,8 @@ __device__ __forceinline__ float snakebeta(float x, float a, float ib) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
 __device__ __forceinline__ f32x2 sin_squared2(f32x2 x) {
-    f32x2 k = x * splat2(0.636619772367581343f);
-    k = (f32x2){rintf(k[0]), rintf(k[1])};
-    const f32x2 nk = -k;
+    const f32x2 t = __builtin_elementwise_fma(x, splat2(0.636619772367581343f), splat2(12582912.0f));
+    const f32x2 nk = splat2(12582912.0f) - t;             // -k
     f32x2 r = __builtin_elementwise_fma(nk, splat2(1.57079625129699707031e+00f), x);
     r = __builtin_elementwise_fma(nk, splat2(7.54978941586159635335e-08f), r);
     r = __builtin_elementwise_fma(nk, splat2(5.39030252995776476554e-15f), r);
@@ -83,9 +87,15 @@ __device__ __forceinline__ f32x2 sin_squared2(f32x2 x) {
     p = __builtin_elementwise_fma(p, u, splat2(4.444364085793495e-2f));
     p = __builtin_elementwise_fma(p, u, splat2(-3.33333283662796e-1f));
     p = __builtin_elementwise_fma(p, u, splat2(1.0f));
-    const f32x2 s2 = p * u;
-    const f32x2 c2 = splat2(1.0f) - s2;
-    return (f32x2){(((int)k[0]) & 1) ? c2[0] : s2[0], (((int)k[1]) & 1) ? c2[1] : s2[1]};
+    const f32x2 h = __builtin_elementwise_fma(p, u, splat2(-0.5f));
+    // +-1 with the quadrant's parity (the sum's lowest mantissa bit) as sign: one v_lshl_or_b32 per element.  Written as asm: from the
+    // C expression (bits(t[i]) << 31) | 0x3F800000 on the two elements hipcc 7.2 built ONE such instruction, on element 0, and fed
+    // its result to both halves of the packed fma below (op_sel_hi:[1,0,0]) - tests/test_gpu_numerics.py caught it on pairs that
+    // straddle a quadrant; the 2-vector integer form is right but takes two instructions per element.
+    // (the s_nop: hipcc pads a packed-fp32 result by one state before its next reader and knows nothing about the asm's reads)
+    float s0, s1;
+    asm("s_nop 0\n\tv_lshl_or_b32 %0, %2, 31, 1.0\n\tv_lshl_or_b32 %1, %3, 31, 1.0" : "=&v"(s0), "=v"(s1) : "v"(t[0]), "v"(t[1]));
+    return __builtin_elementwise_fma(h, (f32x2){s0, s1}, splat2(0.5f));
 }
 __device__ __forceinline__ f32x2 snakebeta2(f32x2 x, f32x2 a, f32x2 ib) {
 #pragma clang fp contract(off)
