@@ -365,6 +365,7 @@ struct FlowCtx {
     FlowWg g;
     FlowArgsC a;
     float *red_lin, *red_gru;
+    float *red_chain;        // MULTI: [2][4][NW][256] partial tiles of a group of chains (flow_layer_chains)
     unsigned sb;             // bytes per flow buffer slot: kept in a register (every layer needs it before its first request; a scalar
                              // load there is a cache round trip on the critical path)
     LdsX stash;              // BVC_FLOW_STASH: this wave's operand blocks of the quanta's input
@@ -377,7 +378,6 @@ struct FlowCtx {
     bool pre_now;            // MULTI: the next layer's weights are requested by the LAST chain of a layer only (true otherwise)
     bool probe;              // this lane records layer entry / exit times (bench instrumentation)
     unsigned hopctr;
-    unsigned gructr;         // MULTI: GRU calls so far (slot of the GRU partial sums); 0 otherwise
     // FILL: this wave's partial sums of the products whose inputs exist long before their layer - W_hh h, W_ih[:, H:] phi_z, the
     // h half of dec.0 - computed one quantum at a time in the waits behind other layers
     f32x4 fgh[3], fgi[3], fd0;
@@ -566,15 +566,24 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
     if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 5);
 }
 
-// MULTI: one single-segment layer for ALL chains of this workgroup, software-pipelined across the chains: while chain ci is
-// multiplied, reduced and published, the operand blocks of chain ci+1 are already on their way (fetched without a flag poll -
-// their producers published them while this workgroup was busy with other chains - and verified like every fetch; a block
-// that still holds the sentinel sends the wave through the ordinary wait-and-fetch path).  Same arithmetic, same order per
-// output as flow_layer.
+// MULTI: one single-segment layer for ALL chains of this workgroup.  The chains' products are software-pipelined (while chain ci is
+// multiplied, the operand blocks of chain ci+1 are on their way - fetched without a flag poll: their producers published them while
+// this workgroup was busy with other chains - and verified like every fetch; a block that still holds the sentinel sends the wave
+// through the ordinary wait-and-fetch path) and reduced in GROUPS of up to four chains: four accumulators per wave, ONE reduction
+// barrier per group, then wave k of the group's four publishing waves (0-3 for even groups, 4-7 for odd ones) runs chain k's
+// epilogue while everybody else goes on.  (One barrier and one single-wave epilogue per CHAIN - round 2 - made wave 0 the pole of
+// every chain: its own products, then the epilogue, with seven waves waiting at the next chain's barrier.)  The partial tiles of a
+// group lie in LDS slot (group & 1): the next writers of a slot are two groups away, and a group's partials are only written
+// after ALL its products, whose operands - the previous layer's outputs of those chains from every workgroup, this one included -
+// exist only once the publishing waves have read what they publish.  Same arithmetic, same order per output as flow_layer.
 template <int PER, int EPI, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H, int NW>
 __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const FlowLin l0, int src0, int nb, int ntiles, int out,
                                                   f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN], int mt0, int nch, long long T) {
     static_assert(PER > 1, "narrow inputs take the per-chain path");
+    static_assert(NW == 8, "two sets of four publishing waves");
+    constexpr int GM = 4;                                  // at most four chains per reduction group ...
+    const int G = nch >= 3 ? GM : 1;                       // ... and one with two chains per workgroup (measured: 128 x 5 s 6,390 audio-s/s with
+                                                           // one chain per barrier against 6,250 with both behind one; 256 x 5 s 6,790 / 6,960)
     FlowWg &g = c.g;
     const auto &a = *c.a;
     if (g.ntile >= ntiles) {
@@ -586,10 +595,7 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
     }
     int lane = g.lane;
     const int wave = g.wave;
-    // (opaque per layer: what is derived from the lane - tile offsets, feature indices, their float forms - is then recomputed here
-    // instead of being hoisted out of the frame loop for all fourteen layers and SPILLED; a spill reload in an epilogue waits, in
-    // order, for every prefetch the wave has in flight)
-    asm volatile("" : "+v"(lane));
+    asm volatile("" : "+v"(lane));                         // (see flow_layer)
     const unsigned code = (unsigned)((c.t << 4) | (unsigned)hopid) | 0x80000000u;
     const int n0 = g.ntile * 16 + (lane >> 4) * 4;
     const int kb0 = wave * PER;
@@ -600,12 +606,10 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
         for (int u = 0; u < PER; ++u) wv[u] = wload(ub, (unsigned)lane * 16u, u);
     }
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, mean4 = {0.f, 0.f, 0.f, 0.f}, std4 = {1.f, 1.f, 1.f, 1.f};
-    if (wave == 0) {
-        if (l0.bias) bias4 = *reinterpret_cast<const f32x4 *>(l0.bias + n0);
-        if (EPI == FE_MEL) {
-            mean4 = *reinterpret_cast<const f32x4 *>(a.mean + n0);
-            std4 = *reinterpret_cast<const f32x4 *>(a.stdv + n0);
-        }
+    if (l0.bias) bias4 = *reinterpret_cast<const f32x4 *>(l0.bias + n0);         // (every wave may publish a chain)
+    if (EPI == FE_MEL) {
+        mean4 = *reinterpret_cast<const f32x4 *>(a.mean + n0);
+        std4 = *reinterpret_cast<const f32x4 *>(a.stdv + n0);
     }
     unsigned spins = 0;
     g.mtile = mt0;
@@ -613,62 +617,149 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
     FlowSrc s = flow_wait<PER>(g, bufb, nb, kb0, c.give_up, code, spins);      // the first chain: wait for its producers
     u32x4 xc[PER], xn[PER];
     flow_issue<PER>(g, s, xc);
-    for (int ci = 0; ci < nch; ++ci) {
-        const bool last = ci == nch - 1;
-        g.mtile = mt0 + ci;
-        c.row = g.mtile * 16 + (lane & 15);
-        c.rowok = c.row < a.B;
-        c.fr = (long long)c.row * T + c.t;
-        if (!last) {                                       // the next chain's blocks: requested before this chain's are waited for
-            FlowSrc sn;
-            sn.base = __builtin_amdgcn_readfirstlane(bufb + (unsigned)((g.mtile + 1) * nb + kb0) * 1024u);
-            sn.vl = (unsigned)lane * 16u;
-            flow_issue<PER>(g, sn, xn);
-        } else {
+    for (int g0 = 0, grp = 0; g0 < nch; g0 += G, ++grp) {
+        const int gn = nch - g0 < G ? nch - g0 : G;
+        f32x4 accs[GM];
 #pragma unroll
-            for (int u = 0; u < PER; ++u) xn[u] = (u32x4){0u, 0u, 0u, 0u};
-        }
-        const unsigned ytile = (unsigned)((g.mtile * ntiles + g.ntile) * 1024 + lane * 16);
-        f32x4 add4 = {0.f, 0.f, 0.f, 0.f};
-        float bitsv = 0.0f;
-        if (wave == 0) {
-            if (ADD && c.rowok) add4 = *reinterpret_cast<const f32x4 *>(a.part0 + c.fr * (ntiles * 16) + n0);
-            if (EPI == FE_CODE && a.var_bit && c.rowok) bitsv = a.bits[c.fr];
-        }
-        bool bad = false;
+        for (int k = 0; k < GM; ++k) {
+            accs[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (k < gn) {                                  // (uniform)
+                const int ci = g0 + k;
+                g.mtile = mt0 + ci;
+                if (ci + 1 < nch) {                        // the next chain's blocks: requested before this chain's are waited for
+                    FlowSrc sn;
+                    sn.base = __builtin_amdgcn_readfirstlane(bufb + (unsigned)((g.mtile + 1) * nb + kb0) * 1024u);
+                    sn.vl = (unsigned)lane * 16u;
+                    flow_issue<PER>(g, sn, xn);
+                } else {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) bad |= is_poison4(xc[u]);
-        while (__any(bad) && !c.give_up) {                 // (rare) not published yet, or a flag ahead of its block: wait, fetch again
-            s = flow_wait<PER>(g, bufb, nb, kb0, c.give_up, code, spins);
-            flow_issue<PER>(g, s, xc);
-            bad = false;
+                    for (int u = 0; u < PER; ++u) xn[u] = (u32x4){0u, 0u, 0u, 0u};
+                }
+                bool bad = false;
 #pragma unroll
-            for (int u = 0; u < PER; ++u) bad |= is_poison4(xc[u]);
-            if (++spins > g.spin_limit) {
-                c.give_up = true;
-                if (lane == 0) flow_report(g.status, code);
+                for (int u = 0; u < PER; ++u) bad |= is_poison4(xc[u]);
+                while (__any(bad) && !c.give_up) {         // (rare) not published yet, or a flag ahead of its block: wait, fetch again
+                    s = flow_wait<PER>(g, bufb, nb, kb0, c.give_up, code, spins);
+                    flow_issue<PER>(g, s, xc);
+                    bad = false;
+#pragma unroll
+                    for (int u = 0; u < PER; ++u) bad |= is_poison4(xc[u]);
+                    if (++spins > g.spin_limit) {
+                        c.give_up = true;
+                        if (lane == 0) flow_report(g.status, code);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    const f32x4 xv = __builtin_bit_cast(f32x4, xc[u]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) accs[k] = mfma16(wv[u][e], xv[e], accs[k]);
+                }
+#pragma unroll
+                for (int u = 0; u < PER; ++u) xc[u] = xn[u];
             }
         }
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const f32x4 xv = __builtin_bit_cast(f32x4, xc[u]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = mfma16(wv[u][e], xv[e], acc);
-        }
-        if (PRE_OUT && last) {                             // the next layer's weights travel during the last chain's reduction
+        if (PRE_OUT && g0 + G >= nch) {                    // the next layer's weights travel during the last group's reduction
             const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
             for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
         }
-        float *r = c.red_lin + (c.hopctr & 1u) * (NW * 256);
-        ++c.hopctr;
-        *reinterpret_cast<f32x4 *>(r + (wave * 64 + lane) * 4) = acc;
-        __syncthreads();
-        if (wave == 0) flow_publish<EPI, ADD, REARM_H, NW>(c, hopid, r, n0, ytile, ntiles, out, bias4, add4, mean4, std4, bitsv);
+        // this wave's chain to publish (if any) and its epilogue operands, requested in front of the barrier
+        const int pk = wave - (grp & 1) * GM;              // publishing waves of this group: (grp & 1) * 4 + k
+        const bool pub = pk >= 0 && pk < gn;
+        FlowCtx ce = c;
+        ce.g.mtile = mt0 + g0 + (pub ? pk : 0);
+        ce.row = ce.g.mtile * 16 + (lane & 15);
+        ce.rowok = ce.row < a.B;
+        ce.fr = (long long)ce.row * T + c.t;
+        ce.probe = c.probe && pk == 0 && g0 == 0;
+        f32x4 add4 = {0.f, 0.f, 0.f, 0.f};
+        float bitsv = 0.0f;
+        if (pub) {
+            if (ADD && ce.rowok) add4 = *reinterpret_cast<const f32x4 *>(a.part0 + ce.fr * (ntiles * 16) + n0);
+            if (EPI == FE_CODE && a.var_bit && ce.rowok) bitsv = a.bits[ce.fr];
+        }
+        float *rg = c.red_chain + (grp & 1) * (GM * NW * 256);
 #pragma unroll
-        for (int u = 0; u < PER; ++u) xc[u] = xn[u];
+        for (int k = 0; k < GM; ++k)
+            if (k < gn) *reinterpret_cast<f32x4 *>(rg + ((k * NW + wave) * 64 + lane) * 4) = accs[k];
+        __syncthreads();
+        if (pub) {
+            const unsigned ytile = (unsigned)((ce.g.mtile * ntiles + g.ntile) * 1024 + lane * 16);
+            flow_publish<EPI, ADD, REARM_H, NW>(ce, hopid, rg + pk * (NW * 256), n0, ytile, ntiles, out, bias4, add4, mean4, std4, bitsv);
+        }
     }
+}
+
+// The GRU cell's reduction and epilogue for ONE chain (c.g.mtile / c.row / c.rowok / c.fr say which): gi / gh are this wave's partial
+// gate sums; prefetch: request the next frame's first weights (wn) in front of the first barrier.
+template <bool ENCODE, int PERN, int NW>
+__device__ __forceinline__ void gru_epilogue(const FlowCtx &c, int hopid, int hb, int n0, unsigned ytile, const f32x4 (&gi)[3], const f32x4 (&gh)[3],
+                                             const FlowLin nxt, f32x4 (&wn)[PERN], bool prefetch) {
+    const FlowWg &g = c.g;
+    const auto &a = *c.a;
+    const int lane = g.lane, wave = g.wave;
+    const long long H = (long long)hb * 16;
+    const unsigned hbuf = (unsigned)(FB_H * 2) * c.sb;
+    if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 3);
+    // The cell's epilogue is spread over the waves (one wave doing all of it - 48 partial tiles to sum, two sigmoids and a tanh for
+    // each of its four outputs per lane - took 1.5 us with seven waves idle): wave k < 6 sums quantity k (gi_r, gi_z, gi_n, gh_r,
+    // gh_z, gh_n) over the eight waves and adds its bias, wave j < 4 then evaluates the cell for output j of every lane, wave 0
+    // gathers the four and publishes.  Same operations in the same order per output as the one-wave form.
+    // Their operands are requested now: they arrive while the other waves reach the barrier.
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, p4 = {0.f, 0.f, 0.f, 0.f};
+    float hp = 0.0f;
+    if (wave < 3) {
+        if (ENCODE) b4 = *reinterpret_cast<const f32x4 *>(a.b_ih + wave * H + n0);
+        if (!ENCODE && c.rowok) p4 = *reinterpret_cast<const f32x4 *>(a.part_gru + c.fr * 3 * H + wave * H + n0);
+    } else if (wave < 6) {
+        b4 = *reinterpret_cast<const f32x4 *>(a.b_hh + (wave - 3) * H + n0);
+    }
+    // this workgroup's own block of h(t): written by itself a frame ago (or the initial state); wave j takes element j of each lane
+    if (wave < 4) hp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g.rs, hbuf + c.par * c.sb + ytile + (unsigned)wave * 4u, 0, AUX_SC1));
+    if (prefetch) {    // the first layer of the next frame (after the last frame a harmless extra request: no value is carried across)
+        const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
+#pragma unroll
+        for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
+    }
+    float *red_gru = c.red_gru;
+    float *red2 = c.red_lin + (c.hopctr & 1u) * (NW * 256);            // [6][256] sums | [256] outputs: the layer partials' free slot
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        *reinterpret_cast<f32x4 *>(red_gru + ((wave * 6 + q) * 64 + lane) * 4) = gi[q];
+        *reinterpret_cast<f32x4 *>(red_gru + ((wave * 6 + 3 + q) * 64 + lane) * 4) = gh[q];
+    }
+    __syncthreads();
+    if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 4);
+    if (wave < 6) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(red_gru + (wave * 64 + lane) * 4);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4 *>(red_gru + ((w * 6 + wave) * 64 + lane) * 4);
+        v += b4;                                           // gi: (sum + b_ih) + the pre-computed phi_z part; gh: sum + b_hh
+        if (wave < 3) v += p4;
+        *reinterpret_cast<f32x4 *>(red2 + (wave * 64 + lane) * 4) = v;
+    }
+    __syncthreads();
+    if (wave < 4) {
+        float sgm[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sgm[k] = red2[(k * 64 + lane) * 4 + wave];
+        const float rg = sigmoid1(sgm[3] + sgm[0]);
+        const float zg = sigmoid1(sgm[4] + sgm[1]);
+        const float ng = tanhf(sgm[2] + rg * sgm[5]);
+        red2[6 * 256 + lane * 4 + wave] = (hp - ng) * zg + ng;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const f32x4 hn = *reinterpret_cast<const f32x4 *>(red2 + 6 * 256 + lane * 4);
+        if (a.all_h && c.rowok && c.t + 1 < a.T) *reinterpret_cast<f32x4 *>(a.all_h + (c.fr + 1) * H + n0) = hn;   // all_h[:, t+1], bvrnn.py:205
+        // h(t)'s slot is NOT re-armed here: other workgroups may still be reading h(t) in their own GRU layer.  It is re-armed
+        // by the second layer of frame t+1 (REARM_H), whose inputs prove that every workgroup has left frame t.
+        __builtin_amdgcn_raw_buffer_store_b128(publishable(hn, c.rowok), g.rs, hbuf + (c.par ^ 1u) * c.sb + ytile, 0, AUX_SC1);
+        flow_stamp(c, hopid, 1);
+    }
+    // red_gru is single-buffered, also when chains are interleaved (MULTI): its next writers are past this call's three barriers,
+    // the partials' readers between the first and the second
 }
 
 // GRU cell (PyTorch gate order r, z, n; bvrnn.py:206,227): gh = W_hh h, gi = W_ih [phi_x_gen ; phi_z]; in decode the
@@ -757,65 +848,90 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
             else                        gru_round<PER, HALF>(wr[i & 1], xa, h0, gi);
         }
     }
-    if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 3);
-    // The cell's epilogue is spread over the waves (one wave doing all of it - 48 partial tiles to sum, two sigmoids and a tanh for
-    // each of its four outputs per lane - took 1.5 us with seven waves idle): wave k < 6 sums quantity k (gi_r, gi_z, gi_n, gh_r,
-    // gh_z, gh_n) over the eight waves and adds its bias, wave j < 4 then evaluates the cell for output j of every lane, wave 0
-    // gathers the four and publishes.  Same operations in the same order per output as the one-wave form.
-    // Their operands are requested now: they arrive while the other waves reach the barrier.
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, p4 = {0.f, 0.f, 0.f, 0.f};
-    float hp = 0.0f;
-    if (wave < 3) {
-        if (ENCODE) b4 = *reinterpret_cast<const f32x4 *>(a.b_ih + wave * H + n0);
-        if (!ENCODE && c.rowok) p4 = *reinterpret_cast<const f32x4 *>(a.part_gru + c.fr * 3 * H + wave * H + n0);
-    } else if (wave < 6) {
-        b4 = *reinterpret_cast<const f32x4 *>(a.b_hh + (wave - 3) * H + n0);
-    }
-    // this workgroup's own block of h(t): written by itself a frame ago (or the initial state); wave j takes element j of each lane
-    if (wave < 4) hp = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(g.rs, hbuf + c.par * c.sb + ytile + (unsigned)wave * 4u, 0, AUX_SC1));
-    if (c.pre_now) {   // the first layer of the next frame (after the last frame a harmless extra request: no value is carried across)
-        const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
+    gru_epilogue<ENCODE, PERN, NW>(c, hopid, hb, n0, ytile, gi, gh, nxt, wn, c.pre_now);
+}
+
+// MULTI: the GRU cell for the chains of this workgroup, two chains at a time: a round's weights (two k-blocks x three gates, streamed
+// through two register sets as in flow_gru) are multiplied with BOTH chains' operand blocks, so the 576 KiB (encode; decode 384) of
+// gate weights per workgroup cross the compute unit's memory path once per pair instead of once per chain - they were a third of
+// everything a workgroup requested per frame.  Per chain and wave the same products in the same order as flow_gru (segments h,
+// phi_z, phi_x; k ascending), hence the same bits; the cells' epilogues run one after the other (gru_epilogue).
+template <int PER, bool ENCODE, int PERN, int NW>
+__device__ __forceinline__ void flow_gru_chains(FlowCtx &c, int hopid, int hb, const FlowLin nxt, f32x4 (&wn)[PERN], int mt0, int nch, long long T) {
+    static_assert(PER == 8, "interleaved chains are built for h_dim 1024");
+    FlowWg &g = c.g;
+    const auto &a = *c.a;
+    if (g.ntile >= hb) {
 #pragma unroll
-        for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
+        for (int u = 0; u < PERN; ++u) wn[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        return;
     }
-    float *red_gru = c.red_gru + (c.gructr & 1u) * (NW * 6 * 256);      // (two slots only when chains are interleaved: MULTI)
-    float *red2 = c.red_lin + (c.hopctr & 1u) * (NW * 256);            // [6][256] sums | [256] outputs: the layer partials' free slot
+    int lane = g.lane;
+    const int wave = g.wave;
+    asm volatile("" : "+v"(lane));                         // (see flow_layer)
+    const unsigned code = (unsigned)((c.t << 4) | (unsigned)hopid) | 0x80000000u;
+    const int n0 = g.ntile * 16 + (lane >> 4) * 4;
+    const unsigned hbuf = (unsigned)(FB_H * 2) * c.sb;
+    constexpr int HALF = 2, RPS = PER / HALF, NSEG = ENCODE ? 3 : 2, NR = NSEG * RPS;
+    const int kb0 = wave * PER;
+    const unsigned l16 = (unsigned)lane * 16u;
+    flow_stamp(c, hopid, 0);
+    for (int p0 = 0; p0 < nch; p0 += 2) {
+        const bool two = p0 + 1 < nch;                     // (uniform) an odd last chain goes alone: its partner's products are skipped
+        FlowWg gA = g, gB = g;
+        gA.mtile = mt0 + p0;
+        gB.mtile = mt0 + p0 + (two ? 1 : 0);
+        f32x4 giA[3], ghA[3], giB[3], ghB[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        *reinterpret_cast<f32x4 *>(red_gru + ((wave * 6 + q) * 64 + lane) * 4) = gi[q];
-        *reinterpret_cast<f32x4 *>(red_gru + ((wave * 6 + 3 + q) * 64 + lane) * 4) = gh[q];
-    }
-    __syncthreads();
-    if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 4);
-    if (wave < 6) {
-        f32x4 v = *reinterpret_cast<const f32x4 *>(red_gru + (wave * 64 + lane) * 4);
+        for (int q = 0; q < 3; ++q) giA[q] = ghA[q] = giB[q] = ghB[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const GPtr uh = uniform_ptr(a.w_hh, ((size_t)g.ntile * hb + kb0) * 3 * g.wmul);
+        const GPtr uz = uniform_ptr(a.w_ihz, ((size_t)g.ntile * 2 * hb + kb0) * 3 * g.wmul);
+        const GPtr ux = uniform_ptr(a.w_ihx, ((size_t)g.ntile * 2 * hb + kb0) * 3 * g.wmul);
+        u32x4 xA[PER], xB[PER];
+        f32x4 wr[2][HALF][3];
+        gru_issue_w<HALF>(uh, l16, 0, wr[0]);
+        gru_issue_known<PER>(gA, hbuf + c.par * c.sb, hb, xA);      // h(t) of both chains: complete since the frame began
+        gru_issue_known<PER>(gB, hbuf + c.par * c.sb, hb, xB);
 #pragma unroll
-        for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4 *>(red_gru + ((w * 6 + wave) * 64 + lane) * 4);
-        v += b4;                                           // gi: (sum + b_ih) + the pre-computed phi_z part; gh: sum + b_hh
-        if (wave < 3) v += p4;
-        *reinterpret_cast<f32x4 *>(red2 + (wave * 64 + lane) * 4) = v;
+        for (int i = 0; i < NR; ++i) {
+            const int sg = i / RPS, h0 = (i % RPS) * HALF;
+            if (i + 1 < NR) {
+                const int sn = (i + 1) / RPS, hn0 = ((i + 1) % RPS) * HALF;
+                gru_issue_w<HALF>(sn == 0 ? uh : ((ENCODE && sn == 1) ? uz : ux), l16, hn0, wr[(i + 1) & 1]);
+            }
+            // a chain's operand blocks of the NEXT segment are requested as soon as its last round of this one is multiplied: they
+            // travel under the partner's round (phi_x(d_t), produced last, is waited for, fetched and verified; h and phi_z are known)
+            const bool seg_end = (i % RPS == RPS - 1) && i + 1 < NR;
+            const bool next_fresh = (i + 1) / RPS == NSEG - 1;
+            if (sg == 0) gru_round<PER, HALF>(wr[i & 1], xA, h0, ghA);
+            else         gru_round<PER, HALF>(wr[i & 1], xA, h0, giA);
+            if (seg_end) {
+                if (next_fresh) gru_fetch_fresh<PER>(gA, (unsigned)(FB_G3 * 2 + c.par) * c.sb, hb, xA, c.give_up, code);
+                else            gru_issue_known<PER>(gA, (unsigned)(FB_Q3 * 2 + c.par) * c.sb, hb, xA);
+            }
+            if (two) {
+                if (sg == 0) gru_round<PER, HALF>(wr[i & 1], xB, h0, ghB);
+                else         gru_round<PER, HALF>(wr[i & 1], xB, h0, giB);
+            }
+            if (seg_end) {
+                if (next_fresh) { if (two) gru_fetch_fresh<PER>(gB, (unsigned)(FB_G3 * 2 + c.par) * c.sb, hb, xB, c.give_up, code); }
+                else            gru_issue_known<PER>(gB, (unsigned)(FB_Q3 * 2 + c.par) * c.sb, hb, xB);
+            }
+        }
+        // the two cells' epilogues, one after the other (one set of partial tiles in LDS)
+        for (int k = 0; k < (two ? 2 : 1); ++k) {
+            FlowCtx ce = c;
+            ce.g.mtile = mt0 + p0 + k;
+            ce.row = ce.g.mtile * 16 + (lane & 15);
+            ce.rowok = ce.row < a.B;
+            ce.fr = (long long)ce.row * T + c.t;
+            ce.probe = c.probe && p0 == 0 && k == 0;
+            const unsigned ytile = (unsigned)((ce.g.mtile * hb + g.ntile) * 1024 + lane * 16);
+            const bool lastc = p0 + k == nch - 1;
+            if (k == 0) gru_epilogue<ENCODE, PERN, NW>(ce, hopid, hb, n0, ytile, giA, ghA, nxt, wn, lastc);
+            else        gru_epilogue<ENCODE, PERN, NW>(ce, hopid, hb, n0, ytile, giB, ghB, nxt, wn, lastc);
+        }
     }
-    __syncthreads();
-    if (wave < 4) {
-        float sgm[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sgm[k] = red2[(k * 64 + lane) * 4 + wave];
-        const float rg = sigmoid1(sgm[3] + sgm[0]);
-        const float zg = sigmoid1(sgm[4] + sgm[1]);
-        const float ng = tanhf(sgm[2] + rg * sgm[5]);
-        red2[6 * 256 + lane * 4 + wave] = (hp - ng) * zg + ng;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const f32x4 hn = *reinterpret_cast<const f32x4 *>(red2 + 6 * 256 + lane * 4);
-        if (a.all_h && c.rowok && c.t + 1 < a.T) *reinterpret_cast<f32x4 *>(a.all_h + (c.fr + 1) * H + n0) = hn;   // all_h[:, t+1], bvrnn.py:205
-        // h(t)'s slot is NOT re-armed here: other workgroups may still be reading h(t) in their own GRU layer.  It is re-armed
-        // by the second layer of frame t+1 (REARM_H), whose inputs prove that every workgroup has left frame t.
-        __builtin_amdgcn_raw_buffer_store_b128(publishable(hn, c.rowok), g.rs, hbuf + (c.par ^ 1u) * c.sb + ytile, 0, AUX_SC1);
-        flow_stamp(c, hopid, 1);
-    }
-    // one chain: red_gru is single-buffered, its next writers are a whole step (and many barriers) away; interleaved chains
-    // (MULTI) alternate between two slots, so the next writers of this slot are two barriers away
 }
 
 }  // namespace
@@ -848,11 +964,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     FlowCtx c;
     FlowArgsC ap = (FlowArgsC)(unsigned long long)a0;      // device-resident copy of the arguments (flow_set_args_kernel)
     c.a = ap;
-    // LDS: [2][NW][256] layer partials | [NW][6][256] GRU partials (MULTI: two such slots).  Filler kernels: the waves' operand stashes
+    // LDS: [2][NW][256] layer partials | [NW][6][256] GRU partials | MULTI: [2][4][NW][256] partials of a group of chains.  Filler kernels: the waves' operand stashes
     // (NW x 8 KiB) lie over the GRU partials - the stashes are dead from the last quantum (layer 9) to the next frame's first layer,
     // whose operand, h(t+1), exists only after wave 0 has read the partials -, then the parked GRU weights (NW x 6 KiB), then the flag.
     c.red_lin = lds;
     c.red_gru = lds + 2 * NW * 256;
+    c.red_chain = lds + 2 * NW * 256 + NW * 6 * 256;      // (MULTI only: FLOW_LDS_MULTI)
     c.stash = (LdsX)(lds + 2 * NW * 256) + (tid >> 6) * (PERH * 64);
     c.gpark = (LdsX)(lds + 2 * NW * 256 + NW * 8 * 256) + (tid >> 6) * (6 * 64);
     c.pubflag = (volatile unsigned __attribute__((address_space(3))) *)(lds + 2 * NW * 256 + NW * 8 * 256 + NW * 6 * 256);
@@ -893,7 +1010,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     c.rowok = c.row < ap->B;
     c.give_up = false;
     c.pre_now = true;
-    c.gructr = 0;
     c.probe = ap->probe != nullptr && bid == ap->probe_wg && tid == ap->probe_wave * 64;
     c.hopctr = 0;
     const int hb = ap->hb, zb = ap->zb, xb = ap->xb;
@@ -986,7 +1102,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
             FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa, gq));
             flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 12, L(a.px1), FB_G1, hb, hb, FB_G2, wa, L(a.px2), wb, mt0, nch, T);
             flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 13, L(a.px2), FB_G2, hb, hb, FB_G3, wb, L(a.px2), wa, mt0, nch, T);
-            FLOW_EACH_CHAIN(flow_gru<PERH, ENCODE, PERH, false, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa, gq); ++c.gructr);
+            flow_gru_chains<PERH, ENCODE, PERH, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa, mt0, nch, T);
         }
     }
 }
@@ -1005,7 +1121,7 @@ int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s) {
 
 constexpr size_t flow_lds(int nw) { return (size_t)(2 * nw * 256 + nw * 6 * 256) * sizeof(float); }      // 64 KiB with 8 waves
 constexpr size_t FLOW_LDS = flow_lds(8);
-constexpr size_t FLOW_LDS_MULTI = FLOW_LDS + (size_t)8 * 6 * 256 * sizeof(float);      // a second slot of GRU partials
+constexpr size_t FLOW_LDS_MULTI = FLOW_LDS + (size_t)2 * 4 * 8 * 256 * sizeof(float);  // + two slots of four chains' partial tiles: 128 KiB
 constexpr size_t FLOW_LDS_FILL = (size_t)(2 * 8 * 256 + 8 * 8 * 256 + 8 * 6 * 256) * sizeof(float) + 16;       // partials | stashes (over the GRU partials) | parked GRU weights | flag: 128 KiB
 
 template <int PERH, bool ENC>
