@@ -180,13 +180,12 @@ struct FlowArgs {
     int probe_wg, probe_wave;               // which workgroup / wave stamps (BVC_PROBE_WG / BVC_PROBE_WAVE, default 0 / 0)
     int dbg_hot_w;                          // experiments only (BVC_FLOW_HOTW=1): every weight request hits the same blocks (wrong results)
     int MG;                                 // utterance groups (chains) per workgroup; 1 = one chain (B <= 16 * CUs / feature tiles)
-    unsigned *census;                       // != null: residency census only - every workgroup adds 1 to census[0] and waits (bounded by
-                                            // spin_limit) until all gridDim.x have; census[1] counts the workgroups that gave up
     int dbg_withhold;                       // tests only: workgroup 0 returns at once
 };
 int flow_kernels_init();
 int flow_perh(int h_dim);
 int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, bool fill, hipStream_t s);
+int launch_flow_census(unsigned *ctr, int grid, unsigned spin_limit, hipStream_t s);   // ctr[0] arrivals, ctr[1] workgroups that gave up
 int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s);
 
 // ------------------------------------------------------------------ front-end (k_frontend.hip)

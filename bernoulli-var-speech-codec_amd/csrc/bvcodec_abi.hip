@@ -1002,35 +1002,29 @@ int mark_call_end(hipStream_t s) {
 inline float *flow_buf(const Workspace &w, int id, int parity) { return w.flow + (size_t)(id * 2 + parity) * w.flow_slot; }
 
 // One-off at model creation: can a full persistent grid (one workgroup per compute unit the device reports) be resident at
-// once?  The kernel itself is launched in census mode - same registers, same LDS - : every workgroup adds itself to a counter
-// and waits (bounded) until all have.  A CU mask, a partition mode or another tenant of the device that keeps workgroups from
-// becoming co-resident shows up here; the model then stays on the launch-per-layer schedule (flow_resident = false).
+// once?  flow_census_kernel has the recurrence kernels' footprint - 512 threads, every VGPR, the filler kernels' LDS -: every
+// workgroup adds itself to a counter and waits (bounded) until all have.  A CU mask, a partition mode or another tenant of the
+// device that keeps workgroups from becoming co-resident shows up here; the model then stays on the launch-per-layer schedule
+// (flow_resident = false).
 int flow_census(bvc_model *m) {
     m->flow_resident = false;
     const int ntg = flow_grid_tiles(m);
-    const int slots = m->cu_count / ntg;
+    int slots = m->cu_count / ntg;
     if (slots <= 0) return BVC_OK;
     unsigned *ctr = nullptr;
     BVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctr), 64));
     m->allocs.push_back(ctr);
     BVC_HIP_TRY(hipMemset(ctr, 0, 64));
-    FlowArgs *d_args = nullptr;
-    BVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_args), sizeof(FlowArgs)));
-    FlowArgs a;
-    memset(&a, 0, sizeof(a));
-    a.census = ctr;
-    a.MT = slots; a.MG = 1; a.NTG = ntg;
-    const bool over = getenv("BVC_FLOW_CENSUS_OVERSUBSCRIBE") != nullptr;             // tests: a grid the device cannot hold
-    if (over) a.MT = slots + 1;
-    a.spin_limit = 200000u;                     // ~50 ms: a workgroup that has to queue behind a resident one shows up as a time-out
-    int rc = launch_flow(a, d_args, m->flow_perh, true, true, nullptr);
+    if (getenv("BVC_FLOW_CENSUS_OVERSUBSCRIBE")) slots += 1;             // tests: a grid the device cannot hold
+    const int grid = ntg * slots;
+    // ~50 ms: a workgroup that has to queue behind a resident one shows up as a time-out
+    const int rc = launch_flow_census(ctr, grid, 200000u, nullptr);
     hipError_t e = hipDeviceSynchronize();
     unsigned h[2] = {0u, 0u};
     if (e == hipSuccess) e = hipMemcpy(h, ctr, sizeof(h), hipMemcpyDeviceToHost);
-    (void)hipFree(d_args);
     if (rc) return rc;
     BVC_HIP_TRY(e);
-    m->flow_resident = h[0] == (unsigned)(ntg * a.MT) && h[1] == 0u;
+    m->flow_resident = h[0] == (unsigned)grid && h[1] == 0u;
     return BVC_OK;
 }
 

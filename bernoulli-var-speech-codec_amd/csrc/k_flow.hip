@@ -79,6 +79,9 @@ namespace {
 #ifndef BVC_GRU_FAST
 #define BVC_GRU_FAST 0
 #endif
+#ifndef BVC_FLOW_POLL_SLEEP
+#define BVC_FLOW_POLL_SLEEP 1                        // s_sleep units (64 clocks) between two polls of a wave
+#endif
 #ifndef BVC_FLOW_DIAG
 #define BVC_FLOW_DIAG 0
 #endif
@@ -126,7 +129,7 @@ __device__ __forceinline__ FlowSrc flow_wait(const FlowWg &g, unsigned buf, int 
     while (!give_up) {
         const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(g.rs, fl, s.base, AUX_SC1);
         if (!__any(t == FLOW_POISON)) break;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(BVC_FLOW_POLL_SLEEP);
         if (++spins > g.spin_limit) {
             give_up = true;
             if (g.lane == 0) flow_report(g.status, code);
@@ -784,7 +787,6 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
     const unsigned code = (unsigned)((c.t << 4) | (unsigned)hopid) | 0x80000000u;
     const int n0 = g.ntile * 16 + (lane >> 4) * 4;
     const unsigned ytile = (unsigned)((g.mtile * hb + g.ntile) * 1024 + lane * 16);
-    const long long H = (long long)hb * 16;
     const unsigned hbuf = (unsigned)(FB_H * 2) * c.sb;
     flow_stamp(c, hopid, 0);
     f32x4 gi[3], gh[3];
@@ -984,21 +986,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     const int mt0 = (slot % MTG) * MG;
     const int nch = MULTI ? (MT - mt0 < MG ? MT - mt0 : MG) : 1;
     c.g.mtile = mt0;
-    if (ap->census) {                                      // residency census (bvc_model_create): are all workgroups of this grid resident at once?
-        if (tid == 0) {
-            unsigned *ctr = ap->census;
-            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > ap->spin_limit) {            // bounded: a workgroup queued behind a resident one never lets the count complete
-                    __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        return;
-    }
     if (ap->dbg_withhold && bid == 0) return;              // tests: a workgroup that never publishes (its consumers time out)
     if (c.g.ntile >= ap->NTG) return;                      // grid is rounded up to a multiple of 8 feature tiles
     c.g.rs = __builtin_amdgcn_make_buffer_rsrc(ap->flow, 0, (int)(FB_COUNT * 2u * ap->slot_bytes), 0x00020000);
@@ -1107,6 +1094,25 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     }
 }
 
+// Residency census (bvc_model_create): are `gridDim.x` workgroups with the recurrence kernels' footprint - 512 threads, every
+// VGPR of the compute unit, the filler kernels' LDS - resident at once?  Every workgroup adds itself to ctr[0] and waits
+// (bounded) until all have; ctr[1] counts those that gave up.  A kernel of its own, so that no profile mixes it with the
+// recurrence launches.
+__global__ __launch_bounds__(512, 2) void flow_census_kernel(unsigned *ctr, unsigned spin_limit) {
+    asm volatile("; the recurrence kernels' register footprint" ::: "v255");
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > spin_limit) {                    // bounded: a workgroup queued behind a resident one never lets the count complete
+                __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+}
+
 __global__ void fill_u32_kernel(unsigned *p, unsigned v, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -1131,8 +1137,15 @@ static int flow_attr() {
     return BVC_OK;
 }
 
+int launch_flow_census(unsigned *ctr, int grid, unsigned spin_limit, hipStream_t s) {
+    hipLaunchKernelGGL(flow_census_kernel, dim3(grid), dim3(512), FLOW_LDS_FILL, s, ctr, spin_limit);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
 int flow_kernels_init() {
     int rc;
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(flow_census_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_FILL));
     BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<8, true, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_MULTI));
     BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<8, false, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_MULTI));
 

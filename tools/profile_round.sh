@@ -1,16 +1,16 @@
 #!/bin/bash
-# Profiles of the round, run on the GPU box from the repository root (gpurun -- 'bash tools/profile_round.sh r02'):
+# Profiles of the round, run on the GPU box from the repository root (gpurun -- 'bash tools/profile_round.sh r03'):
 #   kernel-trace statistics of the default bench.py workload (headline leg only: one batch at a time, no multi_stream leg), then separate --pmc passes (counters serialise the dispatches,
 #   so they never share a run with the timing) on tools/pmc_probe.py = one 64 x 5 s encode + decode.
 # Results land in gpurun_out/; copy the summaries you want judged into profiles/.
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o default -- python3 $REPO/bench.py --steps 10 --warmup 2 --multi-streams 0 --no-cpu-baseline --no-parity > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o default -- python3 $REPO/bench.py --steps 10 --warmup 2 --multi-streams 0 --no-cpu-baseline --no-parity --no-extra > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats_default.csv
 echo "stats done"
 i=0
