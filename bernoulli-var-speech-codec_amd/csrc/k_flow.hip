@@ -579,9 +579,12 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
 // group lie in LDS slot (group & 1): the next writers of a slot are two groups away, and a group's partials are only written
 // after ALL its products, whose operands - the previous layer's outputs of those chains from every workgroup, this one included -
 // exist only once the publishing waves have read what they publish.  Same arithmetic, same order per output as flow_layer.
-template <int PER, int EPI, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H, int NW>
+// TWO: y = epi(W0 x0 + W1 x1 + bias) - the group's chains are first multiplied with segment 0 (its weights are fetched here, into
+// registers of their own), then with segment 1 (wv), into the same accumulators: per output the order of flow_layer's two segments.
+template <int PER, int EPI, bool ADD, bool PRE_IN, bool PRE_OUT, int PERN, bool REARM_H, int NW, bool TWO = false>
 __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const FlowLin l0, int src0, int nb, int ntiles, int out,
-                                                  f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN], int mt0, int nch, long long T) {
+                                                  f32x4 (&wv)[PER], const FlowLin nxt, f32x4 (&wn)[PERN], int mt0, int nch, long long T,
+                                                  const FlowLin lfirst = FlowLin{nullptr, nullptr, 0, 0}, int srcfirst = 0) {
     static_assert(PER > 1, "narrow inputs take the per-chain path");
     static_assert(NW == 8, "two sets of four publishing waves");
     constexpr int GM = 4;                                  // at most four chains per reduction group ...
@@ -615,23 +618,37 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
         std4 = *reinterpret_cast<const f32x4 *>(a.stdv + n0);
     }
     unsigned spins = 0;
-    g.mtile = mt0;
     flow_stamp(c, hopid, 0);
-    FlowSrc s = flow_wait<PER>(g, bufb, nb, kb0, c.give_up, code, spins);      // the first chain: wait for its producers
+    f32x4 wfirst[TWO ? PER : 1];
+    if (TWO) {
+        const GPtr ub = uniform_ptr(lfirst.w, ((size_t)g.ntile * lfirst.wnb + kb0) * g.wmul);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) wfirst[u] = wload(ub, (unsigned)lane * 16u, u);
+    }
     u32x4 xc[PER], xn[PER];
-    flow_issue<PER>(g, s, xc);
     for (int g0 = 0, grp = 0; g0 < nch; g0 += G, ++grp) {
         const int gn = nch - g0 < G ? nch - g0 : G;
         f32x4 accs[GM];
 #pragma unroll
+        for (int k = 0; k < GM; ++k) accs[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pass = TWO ? 0 : 1; pass < 2; ++pass) {
+        const unsigned bufp = (TWO && pass == 0) ? (unsigned)(srcfirst * 2 + c.par) * c.sb : bufb;
+        const f32x4 (&wp)[TWO ? PER : 1] = wfirst;         // (pass 0 only)
+        // the first chain of this pass (of this group): wait for its producers, request its blocks
+        if (TWO || g0 == 0) {
+            g.mtile = mt0 + g0;
+            FlowSrc s0 = flow_wait<PER>(g, bufp, nb, kb0, c.give_up, code, spins);
+            flow_issue<PER>(g, s0, xc);
+        }
+#pragma unroll
         for (int k = 0; k < GM; ++k) {
-            accs[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (k < gn) {                                  // (uniform)
                 const int ci = g0 + k;
                 g.mtile = mt0 + ci;
-                if (ci + 1 < nch) {                        // the next chain's blocks: requested before this chain's are waited for
-                    FlowSrc sn;
-                    sn.base = __builtin_amdgcn_readfirstlane(bufb + (unsigned)((g.mtile + 1) * nb + kb0) * 1024u);
+                if (TWO ? k + 1 < gn : ci + 1 < nch) {     // the next chain's blocks: requested before this chain's are waited for
+                    FlowSrc sn;                            // (TWO: within the group's pass; else on across the groups)
+                    sn.base = __builtin_amdgcn_readfirstlane(bufp + (unsigned)((g.mtile + 1) * nb + kb0) * 1024u);
                     sn.vl = (unsigned)lane * 16u;
                     flow_issue<PER>(g, sn, xn);
                 } else {
@@ -642,8 +659,8 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
 #pragma unroll
                 for (int u = 0; u < PER; ++u) bad |= is_poison4(xc[u]);
                 while (__any(bad) && !c.give_up) {         // (rare) not published yet, or a flag ahead of its block: wait, fetch again
-                    s = flow_wait<PER>(g, bufb, nb, kb0, c.give_up, code, spins);
-                    flow_issue<PER>(g, s, xc);
+                    const FlowSrc sr = flow_wait<PER>(g, bufp, nb, kb0, c.give_up, code, spins);
+                    flow_issue<PER>(g, sr, xc);
                     bad = false;
 #pragma unroll
                     for (int u = 0; u < PER; ++u) bad |= is_poison4(xc[u]);
@@ -655,13 +672,15 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
 #pragma unroll
                 for (int u = 0; u < PER; ++u) {
                     const f32x4 xv = __builtin_bit_cast(f32x4, xc[u]);
+                    const f32x4 wu = (TWO && pass == 0) ? wp[TWO ? u : 0] : wv[u];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) accs[k] = mfma16(wv[u][e], xv[e], accs[k]);
+                    for (int e = 0; e < 4; ++e) accs[k] = mfma16(wu[e], xv[e], accs[k]);
                 }
 #pragma unroll
                 for (int u = 0; u < PER; ++u) xc[u] = xn[u];
             }
         }
+      }
         if (PRE_OUT && g0 + G >= nch) {                    // the next layer's weights travel during the last group's reduction
             const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
@@ -1077,7 +1096,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                 flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 5, L(a.pz1), FB_Q1, hb, hb, FB_Q2, wa, L(a.pz2), wb, mt0, nch, T);
                 flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 6, L(a.pz2), FB_Q2, hb, hb, FB_Q3, wb, L(a.pz2), wa, mt0, nch, T);
                 // two segments share the weight registers: the first segment's weights are fetched per chain
-                FLOW_EACH_CHAIN(flow_layer<PERH, FE_ELU, true, false, false, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb, gq));
+                {                                          // dec.0 = dec0h . h + dec0z . phi_z: both segments for a group's chains, then one reduction
+                    const GPtr ub = uniform_ptr(a.dec0z.w, ((size_t)c.g.ntile * a.dec0z.wnb + c.g.wave * PERH) * c.g.wmul);
+#pragma unroll
+                    for (int u = 0; u < PERH; ++u) wa[u] = wload(ub, (unsigned)c.g.lane * 16u, u);
+                    FlowLin d0 = L(a.dec0z);
+                    d0.bias = a.dec0h.bias;
+                    flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW, true>(c, 7, d0, FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb, mt0, nch, T, L(a.dec0h), FB_H);
+                }
                 flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 8, L(a.dec1), FB_D1, hb, hb, FB_D2, wb, L(a.dec2), wa, mt0, nch, T);
                 flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.dec2), wb, mt0, nch, T);
             } else {
