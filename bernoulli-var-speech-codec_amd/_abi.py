@@ -99,7 +99,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.bvc_abi_version() != 1:
+        if lib.bvc_abi_version() != 2:
             raise BvcError("libbvcodec_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -1794,6 +1794,7 @@ int bvc_vocoder_stream_reset(bvc_vocoder_stream *st, void *stream) {
 int bvc_vocoder_stream_push(bvc_vocoder_stream *st, const float *d_mel, int32_t k, float out_scale_div, float *d_wav,
                             void *stream) {
     if (!st || !d_mel || !d_wav) { set_error("null argument"); return BVC_EINVAL; }
+    if (int st_ = sticky_status(st->m)) return st_;
     if (k <= 0 || k > st->kmax) { set_error("bvc_vocoder_stream_push: k=%d outside 1..%d", (int)k, st->kmax); return BVC_EINVAL; }
     return stream_push(st, d_mel, k, out_scale_div, d_wav, (hipStream_t)stream);
 }
@@ -1859,6 +1860,7 @@ int bvc_stream_codec_buffers(bvc_stream_codec *st, float **d_in, float **d_codes
 
 int bvc_stream_codec_tick(bvc_stream_codec *st, int32_t *n_frames, void *stream) {
     if (!st) { set_error("null stream codec"); return BVC_EINVAL; }
+    if (int st_ = sticky_status(st->m)) return st_;
     const bvc_config &c = st->m->cfg;
     hipStream_t s = (hipStream_t)stream;
     const int B = st->B;

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define BVC_ABI_VERSION 1
+#define BVC_ABI_VERSION 2   /* 2: + bvc_model_get_option, bvc_flow_fence, bvc_kprobe_read_span; recurrence option takes 2 (auto); status word reported by every compute entry */
 
 enum {
     BVC_OK = 0,

@@ -20,7 +20,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/bvcodec.h but not exported"
     assert declared == set(_abi.SIGNATURES), declared ^ set(_abi.SIGNATURES)
-    assert lib.bvc_abi_version() == 1
+    assert lib.bvc_abi_version() == 2
 
 
 def test_config_struct_layout_matches_header():
