@@ -145,7 +145,7 @@ def test_concurrent_stream_picker():
     assert len(bdist.concurrent_streams(2, dev)) == 2
 
 
-@pytest.mark.parametrize("B,graph", [(3, True), (40, True), (3, False)])
+@pytest.mark.parametrize("B,graph", [(3, True), (40, True), (3, False), (256, True)])      # 256 streams: BASELINE configs[4]'s own size
 def test_whole_hop_codec_equals_offline_and_oracle(model, B, graph, monkeypatch):
     """bvc_stream_codec_tick (BASELINE configs[4]: 441-sample hops, the tick replayed from a hipGraph once warm) against
     the offline path AND, directly, against the CPU oracle."""
