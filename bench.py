@@ -72,8 +72,11 @@ ROCPROF_SUMMARY = _latest("kernel_stats_default.csv")
 PMC_SUMMARY = _latest("pmc_per_launch.csv")
 
 
-def flops_per_step(conf, B, T, mode):
-    """Algorithmic FLOPs (2*MAC) of one step per kernel family -> {family: (flops, launches)}."""
+def flops_per_step(conf, B, T, mode, fold=True):
+    """Algorithmic FLOPs (2*MAC) of one step per kernel family -> {family: (flops, launches)}.
+    fold: the persistent decode kernel runs phi_x.0(norm(dec.6(u))) as one folded H x H layer and dec.6 itself as a tenth batched
+    GEMM (library default).  Counted are the REFERENCE's products: phi_x.0 as X*H in the recurrence (not the H*H the
+    folded layer really multiplies), dec.6 where it now runs (batched)."""
     H, Z, X = conf["h_dim"], conf["z_dim"], conf["num_mels"]
     # recurrence, per frame and utterance.  encode: enc.0 (h half), enc.2, enc.4, phi_z x3, dec.0 (both halves), dec.2/4/6,
     # phi_x x3, GRU (W_ih 3Hx2H, W_hh 3HxH).  decode: dec.0 (h half), dec.2/4/6, phi_x x3, GRU (W_ih[:, :H], W_hh)
@@ -82,6 +85,9 @@ def flops_per_step(conf, B, T, mode):
     # batched over all frames.  encode: phi_x + enc.0[:, :H]; decode: phi_z + dec.0[:, :H] + W_ih[:, H:]
     bat_enc = (X * H + 2 * H * H) + H * H
     bat_dec = (Z * H + 2 * H * H) + H * H + 3 * H * H
+    if fold:
+        rec_dec -= H * X
+        bat_dec += H * X
     v = conf["vocoder_config"]
     ch, rate, voc = v["upsample_initial_channel"], 1, conf["num_mels"] * v["upsample_initial_channel"] * 7
     for u, k in zip(v["upsample_rates"], v["upsample_kernel_sizes"]):
@@ -95,7 +101,7 @@ def flops_per_step(conf, B, T, mode):
     return {
         1: (2.0 * BT * (rec_enc + (rec_dec if full else 0)), 2 if full else 1),
         3: (2.0 * BT * voc if full else 0.0, 1 + len(v["upsample_rates"]) * (1 + 9)),   # conv_pre + per stage: ConvT + 9 fused AMP iterations
-        4: (2.0 * BT * (bat_enc + (bat_dec if full else 0)), 9 if full else 4),
+        4: (2.0 * BT * (bat_enc + (bat_dec if full else 0)), (10 if fold else 9) if full else 4),
         5: (2.0 * BT * 5 * 512 * 9 * 1.0, 1),
         6: (2.0 * BT * post if full else 0.0, 1),
     }
@@ -523,7 +529,7 @@ def main():
 
     if rank == 0 and not a.no_roofline:
         lib = _abi.load()
-        fam = flops_per_step(conf, B, T, a.mode)
+        fam = flops_per_step(conf, B, T, a.mode, fold=bool(model.engine().get_option("decode_fold")))
         rows = {}
         for kind in ((1, 3, 4, 5, 6) if full else (1, 4, 5)):               # HIP event pairs around every launch of the family
             _abi.check(lib.bvc_probe_begin(kind, 1, 4096))

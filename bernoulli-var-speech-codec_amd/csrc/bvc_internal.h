@@ -150,7 +150,7 @@ int launch_repack_rows(const float *src, float *dst, long long ld_natural, int r
 // flow + (id * 2 + parity) * slot_bytes, each a fragment-packed [MT16][dim] matrix.
 constexpr unsigned FLOW_POISON = 0xFFFFDEADu;      // a NaN bit pattern no layer may publish as data
 constexpr int FLOW_STAMPS = 6;                     // stamp kinds per layer and frame (k_flow.hip: flow_stamp)
-enum FlowEpi { FE_ELU = 0, FE_CODE = 1, FE_MEL = 2, FE_GRU = 3 };
+enum FlowEpi { FE_ELU = 0, FE_CODE = 1, FE_MEL = 2, FE_GRU = 3, FE_ELU_KEEP = 4 };   // FE_ELU_KEEP: ELU, and the result also goes to FlowArgs::keep
 enum FlowBuf { FB_H = 0, FB_E1, FB_E2, FB_ZC, FB_Q1, FB_Q2, FB_Q3, FB_D1, FB_D2, FB_D3, FB_DN, FB_G1, FB_G2, FB_G3, FB_COUNT };
 struct FlowLin {         // one K-segment of a layer as the persistent kernel sees it (32-/64-bit fields: scalar loads)
     const float *w;      // packed weights [n/16][k/16][lane][4], offset to the segment's first k-block
@@ -181,6 +181,12 @@ struct FlowArgs {
     int dbg_hot_w;                          // experiments only (BVC_FLOW_HOTW=1): every weight request hits the same blocks (wrong results)
     int MG;                                 // utterance groups (chains) per workgroup; 1 = one chain (B <= 16 * CUs / feature tiles)
     int dbg_withhold;                       // tests only: workgroup 0 returns at once
+    // decode with the folded hop (bvcodec_abi.hip: build_bvrnn): dec.6 has no activation, so phi_x.0(norm(dec.6(u))) is ONE affine map
+    // of u = ELU(dec.4(.)) followed by the ELU: pxc = (phi_x.0.W diag(1/std) dec.6.W, phi_x.0.W ((dec.6.b - mean) / std) + phi_x.0.b).
+    // The kernel then runs dec.4 -> pxc -> phi_x.2 ... (one wide layer instead of the two narrow hops dec.6, phi_x.0), stores u for
+    // all frames in `keep` (B,T,H), and dec.6 itself - the decoder's output - is one batched GEMM over `keep` behind the launch.
+    FlowLin pxc;                            // w == null: the layers as the reference lists them
+    float *keep;
 };
 int flow_kernels_init();
 int flow_perh(int h_dim);

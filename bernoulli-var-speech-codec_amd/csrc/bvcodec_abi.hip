@@ -108,6 +108,11 @@ struct bvc_model {
     unsigned flow_spin_limit = 4000000u;   // polls before a wait gives up (> 1 s: only a workgroup that never became resident gets there)
     int flow_debug_withhold = 0;        // tests only: workgroup 0 of a persistent launch returns at once (its peers time out)
     int flow_debug_nofill = 0;          // tests only: no filler quanta (the plain layer program)
+    // decode_fold (default 1): the persistent DECODE kernel runs phi_x.0(norm(dec.6(u))) - three maps without a non-linearity between
+    // them (bvrnn.py:80, :226) - as the one affine map px0_dec3 (folded in float64 at model creation) and dec.6 itself, the decoder's
+    // output, as one batched GEMM behind the launch.  Encode keeps the reference's layers (codes stay bit-exact by construction).
+    Linear px0_dec3{};
+    int decode_fold = 1;
 
     ~bvc_model() {
         for (auto &g : graphs) { (void)hipGraphExecDestroy(g.exec1); (void)hipGraphExecDestroy(g.execN); if (g.idle) (void)hipEventDestroy(g.idle); }
@@ -339,6 +344,30 @@ int build_bvrnn(bvc_model *m, const TensorMap &tm) {
         for (int i = 0; i < 3; ++i)
             if ((rc = load_linear(m, tm, "prior." + std::to_string(2 * i), H, pr_out[i], &m->prior[i]))) return rc;
         m->has_prior = true;
+    }
+    {   // px0_dec3: W = phi_x.0.W diag(1/std) dec.6.W  (H x H),  b = phi_x.0.W ((dec.6.b - mean) / std) + phi_x.0.b, in float64
+        const float *wp0 = tm.at("phi_x.0.weight")->h_data, *bp0 = tm.at("phi_x.0.bias")->h_data;      // [H][X], [H]
+        const float *wd6 = tm.at("dec.6.weight")->h_data, *bd6 = tm.at("dec.6.bias")->h_data;          // [X][H], [X]
+        const float *mean = tm.at("mean_mel")->h_data, *stdv = tm.at("std_mel")->h_data;
+        std::vector<float> wc((size_t)H * H), bc((size_t)H);
+        std::vector<double> row((size_t)H);
+        for (int n = 0; n < H; ++n) {
+            std::fill(row.begin(), row.end(), 0.0);
+            double b = (double)bp0[n];
+            for (int j = 0; j < X; ++j) {
+                const double f = (double)wp0[(size_t)n * X + j] / (double)stdv[j];
+                b += f * ((double)bd6[j] - (double)mean[j]);
+                const float *wr = wd6 + (size_t)j * H;
+                for (int k = 0; k < H; ++k) row[k] += f * (double)wr[k];
+            }
+            for (int k = 0; k < H; ++k) wc[(size_t)n * H + k] = (float)row[k];
+            bc[n] = (float)b;
+        }
+        if (getenv("BVC_DECODE_FOLD") && getenv("BVC_DECODE_FOLD")[0] == '0') m->decode_fold = 0;     // A/B runs (tools/flow_variants.py)
+        m->px0_dec3.in = H; m->px0_dec3.out = H;
+        m->px0_dec3.w = nullptr;                                   // (only the recurrent kernels use it)
+        if ((rc = upload(m, pack_linear(wc.data(), H, H), &m->px0_dec3.wp))) return rc;
+        if ((rc = upload(m, bc, &m->px0_dec3.b))) return rc;
     }
     if (!(t = find(tm, "rnn.weight_ih_l0", (int64_t)3 * H * 2 * H))) return BVC_EMISSING;
     if ((rc = upload(m, pack_linear(t->h_data, 3 * H, 2 * H), &m->w_ih))) return rc;
@@ -912,6 +941,7 @@ void flow_layers(const bvc_model *m, bool encode, FlowArgs *a) {
     a->px0 = flin(m->phi_x[0]);
     a->px1 = flin(m->phi_x[1]);
     a->px2 = flin(m->phi_x[2]);
+    if (!encode && m->decode_fold && m->px0_dec3.wp) a->pxc = flin(m->px0_dec3);
     a->w_hh = m->w_hh_il;
     a->w_ihx = m->w_ih_il;
     a->w_ihz = m->w_ih_il + (size_t)hb * 3 * 256;
@@ -1056,6 +1086,7 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, int chains, co
     a.part0 = w.part_dec0;
     a.part_gru = encode ? nullptr : w.part_gru;
     a.codes = d_codes; a.prob = d_prob; a.bits = d_bits; a.all_h = d_all_h; a.mel = d_mel;
+    a.keep = w.pxB;                             // folded decode: ELU(dec.4) of all frames (pxB is idle once the batched phi_z layers are through)
     a.mean = m->mean_mel; a.stdv = m->std_mel;
     a.var_bit = m->cfg.var_bit;
     a.status = m->d_status;
@@ -1090,6 +1121,9 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, int chains, co
         ++g_flow_n[dev];
     }
     if (d_hT && (rc = launch_repack_rows(flow_buf(w, FB_H, (int)(T & 1)), d_hT, H, B, H, 1, s))) return rc;
+    // folded decode: the decoder's output dec.6(u_t) for all frames at once (bvrnn.py:224-225)
+    if (a.pxc.w && d_mel &&
+        (rc = launch_gemm_batched(w.pxB, H, m->dec[3].w, H, m->dec[3].b, (int)((long long)B * T), X, H, 0, d_mel, X, s))) return rc;
     return BVC_OK;
 }
 
@@ -1931,6 +1965,10 @@ int bvc_model_set_option(bvc_model *m, const char *name, int32_t value) {
         m->flow_debug_withhold = value != 0;
         return BVC_OK;
     }
+    if (strcmp(name, "decode_fold") == 0) {                // 1 (default): dec.6 -> norm -> phi_x.0 as one layer in the persistent decode kernel
+        m->decode_fold = value != 0;
+        return BVC_OK;
+    }
     if (strcmp(name, "flow_debug_nofill") == 0) {          // tests only: the layer program without filler quanta
         m->flow_debug_nofill = value != 0;
         return BVC_OK;
@@ -1962,6 +2000,7 @@ int bvc_flow_fence(void *stream) {
 int bvc_model_get_option(const bvc_model *m, const char *name, int32_t *value) {
     if (!m || !name || !value) { set_error("bvc_model_get_option: null argument"); return BVC_EINVAL; }
     if (strcmp(name, "recurrence") == 0) { *value = m->recurrence; return BVC_OK; }
+    if (strcmp(name, "decode_fold") == 0) { *value = m->decode_fold; return BVC_OK; }
     if (strcmp(name, "flow_resident") == 0) { *value = m->flow_resident ? 1 : 0; return BVC_OK; }       // result of the residency census
     if (strcmp(name, "flow_supported") == 0) { *value = m->flow_perh > 0 ? 1 : 0; return BVC_OK; }    // h_dim laid out for the persistent kernel
     if (strcmp(name, "compute_units") == 0) { *value = m->cu_count; return BVC_OK; }

@@ -575,6 +575,7 @@ __global__ __launch_bounds__(256, 2) void gemm_batched_lds_kernel(const float *_
                                                                   int K, float *__restrict__ y, long long ldy,
                                                                   long long frames_T, int mt16, int out_mode, int m_off) {
     constexpr int BK = 32, LDT = BK + 4;                 // floats per LDS row
+    static_assert(BM == 128 || BM == 64 || BM == 32, "tile heights");
     constexpr int MI = BM / 32;                          // 16-row MFMA tiles per wave (waves: 2 along M x 2 along N)
     constexpr int PA = BM / 32;                          // staging passes of 32 rows for the A operand
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A BMxLDT | B 128xLDT]
@@ -706,8 +707,10 @@ int launch_gemm_batched(const float *x, long long ldx, const float *w, long long
         if (!attr) {
             const void *ks[] = {(const void *)gemm_batched_lds_kernel<0, 128, false>, (const void *)gemm_batched_lds_kernel<1, 128, false>,
                                 (const void *)gemm_batched_lds_kernel<0, 64, false>,  (const void *)gemm_batched_lds_kernel<1, 64, false>,
+                                (const void *)gemm_batched_lds_kernel<0, 32, false>,  (const void *)gemm_batched_lds_kernel<1, 32, false>,
                                 (const void *)gemm_batched_lds_kernel<0, 128, true>,  (const void *)gemm_batched_lds_kernel<1, 128, true>,
-                                (const void *)gemm_batched_lds_kernel<0, 64, true>,   (const void *)gemm_batched_lds_kernel<1, 64, true>};
+                                (const void *)gemm_batched_lds_kernel<0, 64, true>,   (const void *)gemm_batched_lds_kernel<1, 64, true>,
+                                (const void *)gemm_batched_lds_kernel<0, 32, true>,   (const void *)gemm_batched_lds_kernel<1, 32, true>};
             for (const void *k : ks) BVC_HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr = true;
         }
@@ -715,13 +718,18 @@ int launch_gemm_batched(const float *x, long long ldx, const float *w, long long
         const bool rv = N % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
         auto launch = [&](auto act_c, auto bm_c, dim3 grid_, int m_off_) {
             constexpr int A_ = decltype(act_c)::value, BM_ = decltype(bm_c)::value;
-            if (rv) hipLaunchKernelGGL((gemm_batched_lds_kernel<A_, BM_, true>), grid_, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, m_off_);
-            else    hipLaunchKernelGGL((gemm_batched_lds_kernel<A_, BM_, false>), grid_, dim3(256), lds, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, m_off_);
+            const size_t lds_ = (size_t)2 * (BM_ + 128) * 36 * sizeof(float);
+            if (rv) hipLaunchKernelGGL((gemm_batched_lds_kernel<A_, BM_, true>), grid_, dim3(256), lds_, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, m_off_);
+            else    hipLaunchKernelGGL((gemm_batched_lds_kernel<A_, BM_, false>), grid_, dim3(256), lds_, s, x, ldx, w, ldw, bias, M, N, K, y, ldy, frames_T, mt16, out_mode, m_off_);
         };
         // Tail: 2 workgroups fit a CU, so the chip takes 512 tiles per round; a grid that ends with a partly filled round
         // (configs[1]: 215 x 8 = 1,720 tiles = 3.36 rounds) pays a whole round for it.  The rows of that last round are
-        // computed with half-height tiles instead (a second launch; the same k order per accumulator, so the same bits).
+        // computed with half-height tiles instead (a second launch; the same k order per accumulator, so the same bits) - or with
+        // quarter-height tiles (three workgroups of 45 KiB LDS per CU: 768 slots) when those still fit one round: a quarter tile
+        // has a quarter of the products but the same 128-column weight stage, so it is about 0.4 of a full tile's time against the
+        // half tile's 0.55 (the balance a stream-K split would buy, without a fix-up pass and with the summation order untouched).
         static const bool no_tail = getenv("BVC_NO_GEMM_TAIL") != nullptr;
+        static const bool no_q = getenv("BVC_NO_GEMM_QUARTER") != nullptr;
         const int ncol = N / 128, rows_blk = (M + 127) / 128;
         const int slots = 512, per_round = slots / ncol > 0 ? slots / ncol : 1;     // row blocks per full round
         int full_blk = rows_blk;
@@ -734,9 +742,16 @@ int launch_gemm_batched(const float *x, long long ldx, const float *w, long long
         }
         if (full_blk < rows_blk) {
             const int m_off = full_blk * 128;
-            dim3 g2(ncol, (M - m_off + 63) / 64);
-            if (act == 1) launch(std::integral_constant<int, 1>(), std::integral_constant<int, 64>(), g2, m_off);
-            else          launch(std::integral_constant<int, 0>(), std::integral_constant<int, 64>(), g2, m_off);
+            const int q_tiles = ncol * ((M - m_off + 31) / 32);
+            if (!no_q && q_tiles <= 768) {
+                dim3 g2(ncol, (M - m_off + 31) / 32);
+                if (act == 1) launch(std::integral_constant<int, 1>(), std::integral_constant<int, 32>(), g2, m_off);
+                else          launch(std::integral_constant<int, 0>(), std::integral_constant<int, 32>(), g2, m_off);
+            } else {
+                dim3 g2(ncol, (M - m_off + 63) / 64);
+                if (act == 1) launch(std::integral_constant<int, 1>(), std::integral_constant<int, 64>(), g2, m_off);
+                else          launch(std::integral_constant<int, 0>(), std::integral_constant<int, 64>(), g2, m_off);
+            }
         }
         BVC_HIP_TRY(hipGetLastError());
         return BVC_OK;

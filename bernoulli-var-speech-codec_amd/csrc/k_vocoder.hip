@@ -235,9 +235,13 @@ __device__ unsigned long long g_phase[16];
 #else
 #define PHASE(i)
 #endif
-// NSPLIT (C = 64, streaming hops): the four waves split the COLUMN tiles and all work on the same MT row tiles
-// (a hop's one or two new frames are a handful of rows: row-split tiles would mostly compute rows nobody reads).
-template <int C, int MT, int OCC, bool ALIAS, bool NSPLIT = false>
+// CS: how many of the four waves lie along the COLUMN tiles (1, 2 or 4); the other 4 / CS lie along the rows.  A wave computes MT row
+// tiles x NT / CS column tiles, a workgroup (4 / CS) * MT * 16 rows.  CS = 1 re-reads every weight fragment in all four waves
+// (from L2: the weight set of a conv does not fit L1) and feeds MT MFMAs with it; with the waves along the columns a fragment is
+// read once per workgroup and feeds CS * MT MFMAs at the same rows per workgroup - the C = 64 stage (180 KB of weights per conv
+// at ks = 11) 2.63 -> 2.36 ms per step with CS = 4, MT = 8.  Streaming hops (a hop's one or two new frames are a handful of
+// rows: row-split tiles would mostly compute rows nobody reads) use CS = 4 with MT = 2.
+template <int C, int MT, int OCC, bool ALIAS, int CS = 1>
 __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
 #ifdef BVC_PHASE_PROBE
     unsigned long long last_ = __builtin_readcyclecounter();
@@ -246,11 +250,11 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     constexpr int S = C + 2;
     constexpr int NT = (C + 15) / 16;
     constexpr int C4 = C / 4;
-    constexpr int TR = (NSPLIT ? 1 : 4) * MT * 16;        // rows computed by each conv phase
-    constexpr int NTL = NSPLIT ? NT / 4 : NT;             // column tiles of one wave
-    static_assert(!NSPLIT || (NT % 4 == 0 && C > 16), "NSPLIT needs four column tiles");
-    constexpr int CGU = NSPLIT ? C4 : (C >= 64) ? 4 : (C4 % 8 == 0) ? 8 : (C4 % 4 == 0) ? 4 : 2;     // k-steps per weight chunk (NSPLIT: one column tile per wave, so a whole tap
-                                                                                                       // fits; offline C = 64: 4 / 8 / 16 measured, 2.63 / 2.60 / 2.65 ms for the stage)
+    constexpr int TR = (4 / CS) * MT * 16;                // rows computed by each conv phase
+    constexpr int NTL = NT / CS;                          // column tiles of one wave
+    static_assert((CS == 1 || CS == 2 || CS == 4) && NT % CS == 0, "the waves along the columns must divide the column tiles");
+    constexpr int CGU = C4 < 16 / NTL ? C4 : 16 / NTL;    // k-steps per weight chunk: 16 fragments per lane and register set (offline C = 64,
+                                                          // CS = 1: 4 / 8 / 16 k-steps measured, 2.63 / 2.60 / 2.65 ms for the stage)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -307,8 +311,8 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     __syncthreads();
     PHASE(0);
 
-    const int mbase = NSPLIT ? 0 : wave * MT * 16;
-    const int nt0 = NSPLIT ? wave * NTL : 0;              // first column tile of this wave
+    const int mbase = (wave / CS) * MT * 16;
+    const int nt0 = (wave % CS) * NTL;                    // first column tile of this wave
     f32x4 acc[MT][NTL];
     auto mma = [&](const float *tile, int d, const float *wp) {
 #pragma unroll
@@ -766,9 +770,9 @@ static int launch_amp8(AmpArgs a, int B, hipStream_t s) {
     }
 }
 
-template <int C, int MT, int OCC, bool ALIAS, bool NSPLIT = false>
+template <int C, int MT, int OCC, bool ALIAS, int CS = 1>
 static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
-    constexpr int TR = (NSPLIT ? 1 : 4) * MT * 16;
+    constexpr int TR = (4 / CS) * MT * 16;
     const int TT = TR - (a.ks - 1);
     a.tiles_per_batch = (int)((a.L - a.row_begin + TT - 1) / TT);
     if (a.tiles_per_batch <= 0) return BVC_OK;
@@ -780,9 +784,9 @@ static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
     a.ntile = ntile;
     {
         static bool attr = false;
-        if (!attr) { BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<C, MT, OCC, ALIAS, NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        if (!attr) { BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(amp_pair_kernel<C, MT, OCC, ALIAS, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     }
-    hipLaunchKernelGGL((amp_pair_kernel<C, MT, OCC, ALIAS, NSPLIT>), dim3((ntile + 7u) & ~7u), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((amp_pair_kernel<C, MT, OCC, ALIAS, CS>), dim3((ntile + 7u) & ~7u), dim3(256), lds, s, a);
     BVC_HIP_TRY(hipGetLastError());
     return BVC_OK;
 }
@@ -805,7 +809,7 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
     // streaming hops compute a few new rows behind a 64-row history: the 128 / 256-row tiles of the offline sweep would spend
     // most of their MFMAs on rows nobody reads, so short windows take the smallest tile (4 waves x 16 rows)
     const long long new_rows = L - a.row_begin;
-    if (win && c1.cin == 64 && new_rows <= 32 - (c1.ks - 1)) return launch_amp_t<64, 2, 2, true, true>(a, B, s);      // 32 rows, waves split the columns
+    if (win && c1.cin == 64 && new_rows <= 32 - (c1.ks - 1)) return launch_amp_t<64, 2, 2, true, 4>(a, B, s);      // 32 rows, waves split the columns
     if (win && c1.cin == 64 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<64, 1, 2, true>(a, B, s);
     if (win && c1.cin == 32 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<32, 1, 3, true>(a, B, s);
     if (c1.cin == 8 && c1.wp2 && c2.wp2 && g_amp8_enabled) {           // full-tile form of the C = 8 stage
@@ -820,8 +824,18 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
     switch (c1.cin) {
         // tile shapes from a measured sweep (tools/voc_stage_times.py): MT = 16-row tiles per wave, OCC = workgroups per CU the
         // register budget is set for, ALIAS = the S2 tile re-uses the LDS of the S1 tile (one more barrier, half the LDS)
-        case 64: return launch_amp_t<64, 2, 2, true>(a, B, s);      // 3.12 -> 2.62 ms per step vs <64,1,2,false>
-        case 32: return launch_amp_t<32, 4, 3, true>(a, B, s);      // 4.96 -> 4.83
+        case 64: {
+            static const int v = getenv("BVC_AMP64") ? atoi(getenv("BVC_AMP64")) : 8;
+            if (v == 0) return launch_amp_t<64, 2, 2, true>(a, B, s);          // waves along the rows: 3.12 -> 2.62 ms per step vs <64,1,2,false>
+            if (v == 24) return launch_amp_t<64, 4, 2, true, 2>(a, B, s);      // two column groups x two row groups
+            return launch_amp_t<64, 8, 2, true, 4>(a, B, s);                   // waves along the columns: 2.63 -> 2.36
+        }
+        case 32: {
+            static const int v = getenv("BVC_AMP32") ? atoi(getenv("BVC_AMP32")) : 0;
+            if (v == 8) return launch_amp_t<32, 8, 3, true, 2>(a, B, s);
+            if (v == 4) return launch_amp_t<32, 4, 3, true, 2>(a, B, s);
+            return launch_amp_t<32, 4, 3, true>(a, B, s);      // 4.96 -> 4.83
+        }
         case 16: return launch_amp_t<16, 2, 4, false>(a, B, s);     // (MT 4 / ALIAS: no gain)
         case 8:  return launch_amp_t<8, 4, 4, true>(a, B, s);       // 3.14 -> 2.74
         default: set_error("amp_pair: unsupported channel count %d", c1.cin); return BVC_EINVAL;

@@ -72,6 +72,32 @@ def test_batched_linear(lib, M, N, K):
     assert (y.cpu().double() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("M,tail_rows", [(11129, 32), (11982, 64)])
+def test_batched_linear_tail_tiles_equal_full_tiles(lib, M, tail_rows):
+    """launch_gemm_batched: the rows of the last, partly filled round of 128-row tiles go out as a second launch of quarter-
+    (87 row blocks: 23 left over) or half-height tiles (94: 30 left over).  Same k order per accumulator: the tail rows must have
+    the bits they get when the same rows are computed alone (all of them in full-height tiles), and be right."""
+    from bvcodec import _abi
+    N = K = 1024
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / np.sqrt(K)
+    b = torch.randn(N, generator=g)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    st = _abi.current_stream(torch.device(DEV))
+    y = torch.full((M, N), float("nan"), device=DEV)
+    _abi.check(lib.bvc_test_linear_batched(_abi.ptr(xd), _abi.ptr(wd), _abi.ptr(bd), M, N, K, 1, _abi.ptr(y), st))
+    m_off = 64 * 128                                         # one full round: 512 slots / 8 column blocks
+    xt = xd[m_off:].contiguous()
+    yt = torch.full((M - m_off, N), float("nan"), device=DEV)
+    _abi.check(lib.bvc_test_linear_batched(_abi.ptr(xt), _abi.ptr(wd), _abi.ptr(bd), M - m_off, N, K, 1, _abi.ptr(yt), st))
+    torch.cuda.synchronize()
+    assert torch.equal(y[m_off:], yt)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(m_off - 100, M)])
+    ref = torch.nn.functional.elu(torch.nn.functional.linear(x[rows].double(), w.double(), b.double()))
+    assert (y[rows].cpu().double() - ref).abs().max().item() < 2e-5
+
+
 # ----------------------------------------------------------------------------------- front-end (A3)
 def _mel_close(got, ref):
     """|d mel_lin| <= 1e-6 + 3e-6 * mel_lin: in quiet bands of tonal input the float32 FFT's own

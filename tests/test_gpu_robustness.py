@@ -65,6 +65,40 @@ def test_persistent_kernel_families_vs_oracle(h_dim, B, nofill):
         model.set_recurrence("auto")
 
 
+@pytest.mark.parametrize("h_dim,B", [(1024, 64), (1024, 130), (256, 20)])
+def test_folded_decode_hop_vs_layer_by_layer_program_and_oracle(h_dim, B):
+    """bvrnn.py:80 / :226: dec.6 has no activation, so phi_x.0(norm(dec.6(u))) is one affine map of u.  The persistent DECODE kernel
+    runs it as one wide layer (`decode_fold`, default on; folded in float64 at model creation) and computes dec.6 itself, the
+    decoder's output, as one batched GEMM behind the launch.  Against the layer-by-layer program of the same kernel and against
+    oracle.bvrnn.decode: same mel^ / h_T up to rounding.  (Encode never folds: codes stay bit-exact by construction.)"""
+    from gpu_common import make_model
+    from oracle import bvrnn as obv
+    model, conf, vr, _ = make_model(True, h_dim)
+    eng = model.engine()
+    assert eng.get_option("decode_fold") == 1
+    rng = np.random.default_rng(7 * h_dim + B)
+    T = 40
+    codes = torch.from_numpy(rng.integers(0, 2, size=(B, T, 64)).astype(np.float32))
+    codes[:, :, 35:] = 0.5                                      # 3 kbit/s mask
+    h0 = torch.from_numpy((0.2 * rng.standard_normal((B, h_dim))).astype(np.float32))
+    try:
+        model.set_recurrence("persistent")
+        mel1, hT1 = model.bvrnn.decode(codes.to(DEV), h0.unsqueeze(0).to(DEV))
+        eng.set_option("decode_fold", 0)
+        mel0, hT0 = model.bvrnn.decode(codes.to(DEV), h0.unsqueeze(0).to(DEV))
+        torch.cuda.synchronize()
+        model.check_status()
+    finally:
+        eng.set_option("decode_fold", 1)
+        model.set_recurrence("auto")
+    assert (mel1 - mel0).abs().max().item() < 2e-5 and (hT1 - hT0).abs().max().item() < 5e-6
+    pick = [0, B // 2, B - 1]
+    d = obv.decode(vr, codes[pick], h0[pick])
+    for mel, hT in ((mel1, hT1), (mel0, hT0)):
+        assert (mel[pick].cpu() - d["mel"]).abs().max().item() < 5e-5
+        assert (hT[0, pick].cpu() - d["h_last"]).abs().max().item() < 5e-6
+
+
 # --------------------------------------------------------------------------- edge shapes
 def test_single_frame_and_zero_length():
     """T = 1 through every stage (the facade cannot produce it: reflect padding needs L > 512, i.e. two frames) and
