@@ -23,6 +23,35 @@ def test_library_exports_every_symbol_the_header_declares():
     assert lib.bvc_abi_version() == 2
 
 
+def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
+    """include/bvcodec.h is the drop-in boundary: it must compile as C99 and as C++ with nothing but the standard headers
+    (no torch / HIP types in the signatures), and a C program must link against the shared library and get an answer
+    from an entry point that needs no device."""
+    import shutil, subprocess
+    from bvcodec import _abi
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "client.c"
+    src.write_text("""#include <stdio.h>
+#include "bvcodec.h"
+int main(void) {
+    bvc_config cfg;
+    (void)cfg;
+    printf("%d %lld %s\\n", (int)bvc_abi_version(), (long long)bvc_workspace_bytes(0, 4, 10), bvc_last_error() ? "err" : "null");
+    return 0;
+}
+""")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
+    lib = _abi.LIB_PATH
+    exe = tmp_path / "client"
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), lib, f"-Wl,-rpath,{os.path.dirname(lib)}",
+                           "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lstdc++"])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    assert out[0] == "2" and out[1] == "0"
+
+
 def test_config_struct_layout_matches_header():
     from bvcodec import _abi
     # 8 int32 + 2 float + 2 int32 + 8 + 8 int32 + 1 + 4 + 12 int32

@@ -70,6 +70,55 @@ def test_four_stream_schedule_equals_serial(recurrence):
             model.set_recurrence("auto")
 
 
+def test_two_models_on_two_host_threads():
+    """include/bvcodec.h: models are independent, one model is not re-entrant.  Two models (different weights), each driven by its
+    own host thread on its own stream (ctypes releases the GIL inside a call, so the library calls really overlap on the host):
+    the persistent launches of the two go through the process-wide ticket one after the other, everything else overlaps; both
+    threads must get bit for bit what the same calls give from one thread."""
+    import threading
+    from gpu_common import make_model
+    from bvcodec import synth
+    models = [make_model(True, 1024, seed=1234)[0], make_model(True, 1024, seed=4321)[0]]
+    B, L, rounds = 48, int(22050 * 0.9), 4
+    xs = [synth.synthetic_speech(B, L, seed=200 + i, kind="speech").to(DEV) for i in range(2)]
+    try:
+        for m in models:
+            m.set_recurrence("persistent")
+        ref = []
+        for m, x in zip(models, xs):
+            codes = m.encode(x, 3000)
+            ref.append((codes, m.decode(codes, L)))
+        torch.cuda.synchronize(DEV)
+        streams = [torch.cuda.Stream(DEV) for _ in models]
+        results, errors = [[] for _ in models], []
+
+        def worker(i):
+            try:
+                with torch.cuda.stream(streams[i]):
+                    for _ in range(rounds):
+                        codes = models[i].encode(xs[i], 3000)
+                        results[i].append((codes, models[i].decode(codes, L)))
+                streams[i].synchronize()
+            except Exception as e:                               # noqa: BLE001 - reported by the assert below
+                errors.append((i, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        torch.cuda.synchronize(DEV)
+        assert not errors, errors
+        for i in range(2):
+            assert len(results[i]) == rounds
+            for codes, wav in results[i]:
+                assert torch.equal(codes, ref[i][0]) and torch.equal(wav, ref[i][1])
+            models[i].check_status()
+    finally:
+        for m in models:
+            m.set_recurrence("auto")
+
+
 def test_many_workspaces_on_one_model():
     """More streams (hence workspaces) than the launch-per-layer schedule's old 16-entry graph cache held."""
     from gpu_common import make_model
