@@ -239,6 +239,7 @@ struct ConvWindow { long long in_bs, out_bs, row_begin, t_origin; };
 // in (B, Lin, cin) channels-last; out (B, Lout, cout).  Output row r reads input rows
 // r - (ks-1)*dil ... r  (rows outside [0,Lin) are zero).  res/acc have the layout of out.
 int conv_kernels_init();
+void set_amp16_enabled(bool on); // C = 16 AMP pairs: persistent kernel with swapped operands (default) or the generic one
 void set_amp8_enabled(bool on);  // C = 8 AMP pairs: two-rows-per-tile kernel (default) or the generic padded one
 int launch_snakebeta_test(const float *x, long long n, float a, float ib, float *y, hipStream_t s);
 int launch_conv_mfma(const ConvLayer &c, const float *in, long long Lin, float *out, long long Lout,

@@ -1973,6 +1973,10 @@ int bvc_model_set_option(bvc_model *m, const char *name, int32_t value) {
         m->flow_debug_nofill = value != 0;
         return BVC_OK;
     }
+    if (strcmp(name, "vocoder_c16_kernel") == 0) {         // 1 (default): C = 16 AMP pairs on the persistent kernel; 0: generic kernel.  Same bits;
+        set_amp16_enabled(value != 0);                     // process-wide, like vocoder_full_tiles
+        return BVC_OK;
+    }
     if (strcmp(name, "vocoder_full_tiles") == 0) {         // 1 (default): C = 8 AMP pairs on the two-rows-per-tile kernel; 0: generic kernel.
         set_amp8_enabled(value != 0);                      // Process-wide (a validation switch: both give the same bits)
         return BVC_OK;

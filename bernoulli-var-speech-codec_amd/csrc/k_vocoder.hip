@@ -515,6 +515,8 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
 // ds_read_b32), one compile-time offset per k-step.
 static bool g_amp8_enabled = getenv("BVC_NO_AMP8") == nullptr;       // bvc_model_set_option("vocoder_full_tiles"): validation switch, process-wide
 void set_amp8_enabled(bool on) { g_amp8_enabled = on; }
+static bool g_amp16_enabled = getenv("BVC_NO_AMP16") == nullptr;     // bvc_model_set_option("vocoder_c16_kernel"): the same kind of switch for the C = 16 stage
+void set_amp16_enabled(bool on) { g_amp16_enabled = on; }
 
 template <int D>
 __device__ __forceinline__ int pair_row(int m) { return (m / D) * (2 * D) + m % D; }
@@ -770,6 +772,227 @@ static int launch_amp8(AmpArgs a, int B, hipStream_t s) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The C = 16 stage on a kernel of its own, in the manner of amp_pair8_kernel: persistent (a workgroup keeps both convs' weights,
+// the biases and the SnakeBeta parameters in registers and walks over tiles; the input rows of its NEXT tile travel under the
+// current tile's convs), taps and dilation at compile time, and the MFMA operands swapped (weights as A, activations as B), so
+// that a lane's four results are four consecutive channels of ONE row: the S2 tile is written as one 16-byte LDS store per row
+// tile and the output (with its residual / running-sum operands) moves as 16 bytes per lane straight from the accumulators -
+// a wave's 16 rows x 64 bytes are one contiguous KiB - with no transposition through LDS.  Row stride 20 floats: the B-operand
+// reads of a wave (16 rows x 4 channels) fall into 64 different banks, and rows stay 16-byte aligned.  Two barriers per tile (the
+// S1 and S2 tiles do not share LDS).  Same taps, same k order per output as amp_pair_kernel<16, ...>: the same bits
+// (tests/test_gpu_parity.py::test_vocoder_c16_kernel_equals_generic).
+template <int KS, int D, int MT>
+struct Amp16Geom {
+    static constexpr int S = 20;
+    static constexpr int TR = 4 * MT * 16;                      // rows per conv phase and workgroup
+    static constexpr int TT = TR - (KS - 1);                    // valid output rows
+    static constexpr int HALO1 = (KS - 1) * D;
+    static constexpr int ROWS1 = TR + HALO1;                    // S1(x) rows [tbase - HALO1, tbase + TR)
+    static constexpr int ROWS2 = TR + KS - 1;                   // S2(u) rows [tbase, tbase + TR) + spare rows read by discarded outputs
+    static constexpr size_t LDS_BYTES = (size_t)(ROWS1 + ROWS2) * S * sizeof(float);
+};
+
+template <int KS, int D, int MT, int OCC>
+__global__ __launch_bounds__(256, OCC) void amp_pair16_kernel(AmpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using G = Amp16Geom<KS, D, MT>;
+    constexpr int C = 16, C4 = 4, S = G::S, TR = G::TR, TT = G::TT;
+    constexpr int NLD = (G::ROWS1 * C4 + 255) / 256;
+    float *t1 = lds, *t2 = lds + G::ROWS1 * S;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    // tiles: as in amp_pair8_kernel (each XCD a contiguous run, its workgroups stride through it)
+    const unsigned per = (a.ntile + 7u) >> 3, nli = gridDim.x >> 3;
+    const unsigned xcd = blockIdx.x & 7u;
+    unsigned li = blockIdx.x >> 3;
+    const unsigned run_end = (xcd + 1u) * per < a.ntile ? (xcd + 1u) * per : a.ntile;
+    if (xcd * per + li >= run_end) return;
+
+    float w1reg[KS][C4], w2reg[KS][C4];
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int c = 0; c < C4; ++c) {
+            w1reg[j][c] = a.w1[(j * C4 + c) * 64 + lane];
+            w2reg[j][c] = a.w2[(j * C4 + c) * 64 + lane];
+        }
+    const f32x4 aa1 = *reinterpret_cast<const f32x4 *>(a.a1 + (tid & 3) * 4);       // phase 1: item idx has channels (idx & 3) * 4 ..; idx & 3 == tid & 3
+    const f32x4 bb1 = *reinterpret_cast<const f32x4 *>(a.ib1 + (tid & 3) * 4);
+    const f32x4 bias1 = *reinterpret_cast<const f32x4 *>(a.b1 + g * 4), aa2 = *reinterpret_cast<const f32x4 *>(a.a2 + g * 4);
+    const f32x4 bb2 = *reinterpret_cast<const f32x4 *>(a.ib2 + g * 4), bias2 = *reinterpret_cast<const f32x4 *>(a.b2 + g * 4);
+    for (int idx = tid; idx < (KS - 1) * S; idx += 256) t2[TR * S + idx] = 0.0f;     // spare rows: never written again
+
+    auto tile_origin = [&](unsigned bid, int &b, long long &t0) {
+        b = (int)(bid / (unsigned)a.tiles_per_batch);
+        t0 = a.row_begin + (long long)(bid - (unsigned)b * (unsigned)a.tiles_per_batch) * TT;
+    };
+    auto load_rows = [&](unsigned bid, f32x4 (&v)[NLD]) {       // x rows [t0 - (KS-1) - HALO1, .. + ROWS1) of tile bid
+        int b; long long t0;
+        tile_origin(bid, b, t0);
+        const float *xb = a.x + (long long)b * a.bs;
+        const long long tfirst = t0 - (KS - 1) - G::HALO1;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            const long long tg = tfirst + (idx >> 2);
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (idx < G::ROWS1 * C4 && tg >= 0 && tg < a.L) v[i] = *reinterpret_cast<const f32x4 *>(xb + tg * C + (idx & 3) * 4);
+        }
+    };
+
+    const int mbase = wave * MT * 16;
+    f32x4 acc[MT];
+    // acc[i][e] = out[row mbase + 16 i + r][channel 4 g + e]; tap j of output row m reads tile row m + j * DD
+    auto conv = [&](auto dd, const float *tile, const float (&wreg)[KS][C4]) {
+        constexpr int DD = decltype(dd)::value;
+        const float *brow = tile + (mbase + r) * S + g;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KS; ++j)
+#pragma unroll
+            for (int c = 0; c < C4; ++c) {
+                float bv[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) bv[i] = brow[(j * DD + i * 16) * S + c * 4];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][c], bv[i], acc[i], 0, 0, 0);
+            }
+    };
+
+    f32x4 v[NLD];
+    load_rows(xcd * per + li, v);
+    for (;;) {
+        const unsigned bid = xcd * per + li;
+        int b; long long t0;
+        tile_origin(bid, b, t0);
+        const long long tbase = t0 - (KS - 1);             // global row of conv1's local output row 0
+
+        // ---- phase 1: S1(x) rows [tbase - HALO1, tbase + TR) into LDS
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < G::ROWS1 * C4) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {                                        // S(0) = 0 keeps the zero padding
+                    const f32x2 o2 = snakebeta2((f32x2){v[i][e], v[i][e + 1]}, (f32x2){aa1[e], aa1[e + 1]}, (f32x2){bb1[e], bb1[e + 1]});
+                    o[e] = o2[0]; o[e + 1] = o2[1];
+                }
+                *reinterpret_cast<f32x4 *>(t1 + (idx >> 2) * S + (idx & 3) * 4) = o;
+            }
+        }
+        li += nli;
+        const bool more = xcd * per + li < run_end;        // (uniform)
+        if (more) load_rows(xcd * per + li, v);             // the next tile's rows travel under this tile's convs
+        __syncthreads();
+
+        // ---- phase 2: u = conv1(S1(x)); S2(u + b1) into its own tile, zero before the start of the signal
+        conv(std::integral_constant<int, D>(), t1, w1reg);
+        {
+            const long long zr64 = -(tbase + a.t_origin);  // local rows before zrow lie before the start of the signal
+            const int zrow = zr64 <= 0 ? 0 : (zr64 > TR ? TR : (int)zr64);      // (the reference pads AFTER the activation)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = mbase + i * 16 + r;
+                const f32x4 u4 = acc[i] + bias1;
+                const f32x2 s01 = snakebeta2((f32x2){u4[0], u4[1]}, (f32x2){aa2[0], aa2[1]}, (f32x2){bb2[0], bb2[1]});
+                const f32x2 s23 = snakebeta2((f32x2){u4[2], u4[3]}, (f32x2){aa2[2], aa2[3]}, (f32x2){bb2[2], bb2[3]});
+                const bool keep = row >= zrow;
+                *reinterpret_cast<f32x4 *>(t2 + row * S + g * 4) = keep ? (f32x4){s01[0], s01[1], s23[0], s23[1]} : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 3: x' = conv2(t2) + b2 + x (+ running sum, / num_kernels): operands requested before the MFMAs, 16 bytes per
+        // lane, straight from / to the accumulator layout (output row m of this lane: global row t0 + m)
+        const long long ob = (long long)b * a.bs + t0 * C;
+        const long long rows_left = a.L - t0;
+        const int nvalid = (int)(rows_left < TT ? rows_left : TT);
+        f32x4 resq[MT], accq[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = mbase + i * 16 + r;
+            const bool ok = row < nvalid;
+            resq[i] = ok ? *reinterpret_cast<const f32x4 *>(a.x + ob + row * C + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            accq[i] = (ok && a.epi >= CE_RES_ACC) ? *reinterpret_cast<const f32x4 *>(a.acc + ob + row * C + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        conv(std::integral_constant<int, 1>(), t2, w2reg);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = mbase + i * 16 + r;
+            if (row >= nvalid) continue;
+            f32x4 o4 = acc[i] + bias2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float o = o4[e] + resq[i][e];                            // x = xt + x      (models.py:119)
+                if (a.epi >= CE_RES_ACC) o = accq[i][e] + o;             // xs += resblock  (models.py:224)
+                if (a.epi == CE_RES_ACC_DIV) o = o / a.divisor;          // xs / num_kernels (models.py:225)
+                o4[e] = o;
+            }
+            *reinterpret_cast<f32x4 *>(a.out + ob + row * C + g * 4) = o4;
+        }
+        if (!more) break;
+    }
+}
+
+template <int KS, int D, int MT, int OCC>
+static int amp16_slots() {
+    static int slots = 0;
+    if (!slots) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(amp_pair16_kernel<KS, D, MT, OCC>), 256,
+                                                         Amp16Geom<KS, D, MT>::LDS_BYTES) != hipSuccess) {
+            set_error("amp_pair16: occupancy query failed");
+            return -1;
+        }
+        slots = (per_cu > 0 ? per_cu : 1) * cus;
+    }
+    return slots;
+}
+template <int KS, int D, int MT, int OCC>
+static int launch_amp16_t(AmpArgs a, int B, hipStream_t s) {
+    using G = Amp16Geom<KS, D, MT>;
+    a.tiles_per_batch = (int)((a.L - a.row_begin + G::TT - 1) / G::TT);
+    if (a.tiles_per_batch <= 0) return BVC_OK;
+    const int slots = amp16_slots<KS, D, MT, OCC>();
+    if (slots <= 0) return BVC_EHIP;
+    ProbeScope probe(PK_CONV, s);
+    const unsigned ntile = (unsigned)(a.tiles_per_batch * (long long)B);
+    a.ntile = ntile;
+    const unsigned grid = ntile < (unsigned)slots ? ((ntile + 7u) & ~7u) : ((unsigned)slots & ~7u);
+    hipLaunchKernelGGL((amp_pair16_kernel<KS, D, MT, OCC>), dim3(grid), dim3(256), G::LDS_BYTES, s, a);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+// OCC: the register budget the taps leave (both convs' weights live in registers: 8 KS floats per lane)
+template <int KS, int MT> struct Amp16Occ { static constexpr int V = MT >= 4 ? 2 : (KS == 3 ? 4 : KS == 7 ? 3 : 2); };
+template <int MT>
+static int launch_amp16(AmpArgs a, int B, hipStream_t s) {
+    switch (a.ks * 8 + a.dil) {
+        case 3 * 8 + 1:  return launch_amp16_t<3, 1, MT, Amp16Occ<3, MT>::V>(a, B, s);
+        case 3 * 8 + 3:  return launch_amp16_t<3, 3, MT, Amp16Occ<3, MT>::V>(a, B, s);
+        case 3 * 8 + 5:  return launch_amp16_t<3, 5, MT, Amp16Occ<3, MT>::V>(a, B, s);
+        case 7 * 8 + 1:  return launch_amp16_t<7, 1, MT, Amp16Occ<7, MT>::V>(a, B, s);
+        case 7 * 8 + 3:  return launch_amp16_t<7, 3, MT, Amp16Occ<7, MT>::V>(a, B, s);
+        case 7 * 8 + 5:  return launch_amp16_t<7, 5, MT, Amp16Occ<7, MT>::V>(a, B, s);
+        case 11 * 8 + 1: return launch_amp16_t<11, 1, (MT > 4 ? 4 : MT), Amp16Occ<11, MT>::V>(a, B, s);      // (88 weight registers: four row tiles at most)
+        case 11 * 8 + 3: return launch_amp16_t<11, 3, (MT > 4 ? 4 : MT), Amp16Occ<11, MT>::V>(a, B, s);      // (88 weight registers: four row tiles at most)
+        case 11 * 8 + 5: return launch_amp16_t<11, 5, (MT > 4 ? 4 : MT), Amp16Occ<11, MT>::V>(a, B, s);      // (88 weight registers: four row tiles at most)
+        default: return -1;                                // not one of the generator's shapes: the generic kernel takes it
+    }
+}
+template <int MT>
+static bool amp16_slots_all() {
+    return amp16_slots<3, 1, MT, Amp16Occ<3, MT>::V>() > 0 && amp16_slots<3, 3, MT, Amp16Occ<3, MT>::V>() > 0 && amp16_slots<3, 5, MT, Amp16Occ<3, MT>::V>() > 0 &&
+           amp16_slots<7, 1, MT, Amp16Occ<7, MT>::V>() > 0 && amp16_slots<7, 3, MT, Amp16Occ<7, MT>::V>() > 0 && amp16_slots<7, 5, MT, Amp16Occ<7, MT>::V>() > 0 &&
+           amp16_slots<11, 1, (MT > 4 ? 4 : MT), Amp16Occ<11, MT>::V>() > 0 && amp16_slots<11, 3, (MT > 4 ? 4 : MT), Amp16Occ<11, MT>::V>() > 0 &&
+           amp16_slots<11, 5, (MT > 4 ? 4 : MT), Amp16Occ<11, MT>::V>() > 0;
+}
+
 template <int C, int MT, int OCC, bool ALIAS, int CS = 1>
 static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
     constexpr int TR = (4 / CS) * MT * 16;
@@ -836,7 +1059,15 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
             if (v == 4) return launch_amp_t<32, 4, 3, true, 2>(a, B, s);
             return launch_amp_t<32, 4, 3, true>(a, B, s);      // 4.96 -> 4.83
         }
-        case 16: return launch_amp_t<16, 2, 4, false>(a, B, s);     // (MT 4 / ALIAS: no gain)
+        case 16: {
+            if (g_amp16_enabled && !win) {                  // offline sweep: the persistent C = 16 kernel
+                // four row tiles per wave (256 rows per workgroup): 2.82 (generic kernel) -> 2.62 ms per step for the stage; two tiles 2.82,
+                // six (KS <= 7) 2.60
+                const int rc16 = launch_amp16<4>(a, B, s);
+                if (rc16 != -1) return rc16;
+            }
+            return launch_amp_t<16, 2, 4, false>(a, B, s);     // (MT 4 / ALIAS: no gain)
+        }
         case 8:  return launch_amp_t<8, 4, 4, true>(a, B, s);       // 3.14 -> 2.74
         default: set_error("amp_pair: unsupported channel count %d", c1.cin); return BVC_EINVAL;
     }
@@ -893,6 +1124,7 @@ int launch_snakebeta_test(const float *x, long long n, float a, float ib, float 
 int conv_kernels_init() {
     int rc;
     if (!amp8_slots_all<1, 4>() || !amp8_slots_all<2, 2>()) return BVC_EHIP;
+    if (!amp16_slots_all<4>()) return BVC_EHIP;
     if ((rc = allow_big_lds<128, 4, 2>())) return rc;
     if ((rc = allow_big_lds<80, 4, 2>())) return rc;
     if ((rc = allow_big_lds<64, 4, 2>())) return rc;

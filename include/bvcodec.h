@@ -111,6 +111,9 @@ void bvc_model_destroy(bvc_model *m);
  *   "vocoder_full_tiles": 1 (default) = the eight-channel generator stage runs on the kernel that packs two output rows into
  *                 one MFMA tile, 0 = on the generic kernel (half of every tile is channel padding).  Same bits either way;
  *                 a validation switch, and process-wide rather than per model.
+ *   "vocoder_c16_kernel": 1 (default) = the sixteen-channel generator stage runs offline on its persistent kernel (weights in
+ *                 registers, next tile's rows under the current tile's convs, 16-byte epilogues), 0 = on the generic kernel.
+ *                 Same bits either way; process-wide, like "vocoder_full_tiles".
  *   "decode_fold": 1 (default) = the persistent DECODE kernel runs phi_x.0((dec.6(u) - mean) / std) - three maps with no
  *                 non-linearity between them (bvrnn.py:80, :226) - as ONE affine map of u (folded in float64 at model creation):
  *                 one wide layer instead of two narrow hops per frame; dec.6(u), the decoder's output, is then one batched GEMM

@@ -364,24 +364,26 @@ def test_vocoder_is_causal(env):
     assert torch.equal(full[:, :, :2560], part[:, :, :2560])
 
 
-def test_vocoder_full_tile_c8_kernel_equals_generic(env):
-    """The C = 8 stage runs on amp_pair8_kernel (two output rows per MFMA tile, k_vocoder.hip); the generic kernel pads the
-    eight channels to sixteen columns.  Every output accumulates the same products in the same order: identical bits, for
+@pytest.mark.parametrize("option", ["vocoder_full_tiles", "vocoder_c16_kernel"])
+def test_vocoder_full_tile_c8_kernel_equals_generic(env, option):
+    """The C = 8 stage runs on amp_pair8_kernel (two output rows per MFMA tile, k_vocoder.hip; the generic kernel pads the
+    eight channels to sixteen columns), the C = 16 stage on amp_pair16_kernel (persistent, operands swapped, 16-byte
+    epilogues).  Every output accumulates the same products in the same order as in the generic kernel: identical bits, for
     lengths that end inside / on / beyond a tile and for more rows than one workgroup tile per utterance."""
     model = env[0]
     eng = model.engine(torch.empty(0, device=DEV))
     rng = np.random.default_rng(11)
     try:
-        for B, T, length in ((3, 9, 10 ** 9), (2, 40, 256 * 40 + 100), (1, 3, 700), (5, 1, 10 ** 9)):
+        for B, T, length in ((3, 9, 10 ** 9), (2, 40, 256 * 40 + 100), (1, 3, 700), (5, 1, 10 ** 9), (70, 33, 256 * 33 - 9)):
             mel = torch.from_numpy((-4 + 1.6 * rng.standard_normal((B, 80, T))).astype(np.float32)).to(DEV)
-            eng.set_option("vocoder_full_tiles", 1)
+            eng.set_option(option, 1)
             a = model.vocoder(mel, length)
-            eng.set_option("vocoder_full_tiles", 0)
+            eng.set_option(option, 0)
             b = model.vocoder(mel, length)
             assert a.shape == b.shape and torch.isfinite(a).all()
-            assert torch.equal(a, b), (B, T, length, (a - b).abs().max().item())
+            assert torch.equal(a, b), (option, B, T, length, (a - b).abs().max().item())
     finally:
-        eng.set_option("vocoder_full_tiles", 1)
+        eng.set_option(option, 1)
 
 
 def test_full_size_config_roundtrip_properties():
