@@ -224,6 +224,8 @@ struct ConvLayer {               // one causal conv as implicit GEMM on fp32 MFM
     int ks;                      // taps
     int dil;
     const float *wp;             // packed B fragments [ks][cin/4][ntiles][64]
+    const float *wp4;            // cin == cout, a multiple of 16, >= 32: [ks][cin/16][ntiles][64][4] - a lane's fragments of four consecutive k-steps as ONE
+                                 // 16-byte granule (amp_pair_kernel's streamed weights: a quarter of the load instructions), else nullptr
     const float *wp2;            // cin == cout == 8 only: two-output-rows-per-tile form [ks+1][2][64] (amp_pair8_kernel), else nullptr
     const float *bias;           // [cout] (for ConvT: bias replicated per phase)
     const float *act_a;          // exp(alpha) per input channel or nullptr (no input activation)

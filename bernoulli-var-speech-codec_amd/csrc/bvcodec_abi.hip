@@ -212,6 +212,22 @@ std::vector<float> pack_conv(const float *W, int cout, int cin, int ks) {
     return p;
 }
 
+// Conv1d weight W[cout][cin][ks] -> [ks][cin/16][ntiles][64][4]: the fragments of pack_conv for four consecutive k-steps side by side
+std::vector<float> pack_conv_k4(const float *W, int cout, int cin, int ks) {
+    const int g4 = cin / 16, ntiles = (cout + 15) / 16;
+    std::vector<float> p((size_t)ks * g4 * ntiles * 64 * 4, 0.0f);
+    for (int j = 0; j < ks; ++j)
+        for (int q = 0; q < g4; ++q)
+            for (int nt = 0; nt < ntiles; ++nt)
+                for (int l = 0; l < 64; ++l)
+                    for (int u = 0; u < 4; ++u) {
+                        const int co = nt * 16 + (l & 15), ci = (q * 4 + u) * 4 + (l >> 4);
+                        if (co < cout)
+                            p[((((size_t)j * g4 + q) * ntiles + nt) * 64 + l) * 4 + u] = W[((size_t)co * cin + ci) * ks + j];
+                    }
+    return p;
+}
+
 // Conv1d weight W[8][8][ks] -> B fragments [ks+1][2][64] of the two-rows-per-tile form (k_vocoder.hip, amp_pair8_kernel):
 // column n = p*8 + co of k-step k holds W[co][ci][k - p] (zero outside the kernel)
 std::vector<float> pack_conv_two_rows(const float *W, int ks) {
@@ -247,6 +263,8 @@ int make_conv(bvc_model *m, const float *W, const float *bias, int nbias_rep, in
     std::vector<float> wp = pack_conv(W, cout, cin, ks);
     if ((rc = upload(m, wp, &c->wp))) return rc;
     c->wp2 = nullptr;
+    c->wp4 = nullptr;
+    if (cin == cout && cin >= 32 && cin % 16 == 0 && alpha && (rc = upload(m, pack_conv_k4(W, cout, cin, ks), &c->wp4))) return rc;
     if (cin == 8 && cout == 8 && (rc = upload(m, pack_conv_two_rows(W, ks), &c->wp2))) return rc;
     std::vector<float> b((size_t)cout);
     const int per = cout / nbias_rep;

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     static_assert((CS == 1 || CS == 2 || CS == 4) && NT % CS == 0, "the waves along the columns must divide the column tiles");
     constexpr int CGU = C4 < 16 / NTL ? C4 : 16 / NTL;    // k-steps per weight chunk: 16 fragments per lane and register set (offline C = 64,
                                                           // CS = 1: 4 / 8 / 16 k-steps measured, 2.63 / 2.60 / 2.65 ms for the stage)
+    constexpr bool W4 = C >= 32 && CGU % 4 == 0;          // streamed weights in 16-byte granules (a.w1 / a.w2 = ConvLayer::wp4)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -323,16 +324,31 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
         const float *wl = wp + lane;
         constexpr int CPT = C4 / CGU;                       // chunks per tap
         const int nch = ks * CPT;
-        float bcur[CGU][NTL], bnxt[CGU][NTL];
-        auto loadb = [&](float (&dstb)[CGU][NTL], int q) {
-            const float *wq = wl + (long long)q * CGU * NT * 64;      // packed [tap][cin/4][ntile][64] is chunk-linear
+        // W4 (C >= 32): the weights come packed [tap][cin/16][ntile][64][4] (ConvLayer::wp4): four k-steps' fragments per 16-byte load
+        constexpr int G4 = W4 ? CGU / 4 : CGU;                 // load granules per column tile and chunk
+        typedef typename std::conditional<W4, f32x4, float>::type BW;
+        BW bcur[G4][NTL], bnxt[G4][NTL];
+        auto loadb = [&](BW (&dstb)[G4][NTL], int q) {
+            if constexpr (W4) {
+                const f32x4 *wq = reinterpret_cast<const f32x4 *>(wp) + (long long)q * G4 * NT * 64 + lane;
 #pragma unroll
-            for (int u = 0; u < CGU; ++u)
+                for (int u = 0; u < G4; ++u)
 #pragma unroll
-                for (int n = 0; n < NTL; ++n) dstb[u][n] = wq[(u * NT + nt0 + n) * 64];
+                    for (int n = 0; n < NTL; ++n) dstb[u][n] = wq[(u * NT + nt0 + n) * 64];
+            } else {
+                const float *wq = wl + (long long)q * CGU * NT * 64;      // packed [tap][cin/4][ntile][64] is chunk-linear
+#pragma unroll
+                for (int u = 0; u < CGU; ++u)
+#pragma unroll
+                    for (int n = 0; n < NTL; ++n) dstb[u][n] = wq[(u * NT + nt0 + n) * 64];
+            }
+        };
+        auto bfrag = [&](const BW (&bw)[G4][NTL], int u, int n) -> float {
+            if constexpr (W4) return bw[u >> 2][n][u & 3];
+            else return bw[u][n];
         };
         // two register sets take turns (no copies): chunk q+1 is in flight while chunk q feeds the MFMAs
-        auto compute = [&](const float (&bw)[CGU][NTL], int q) {
+        auto compute = [&](const BW (&bw)[G4][NTL], int q) {
             const int j = q / CPT, cg0 = (q - j * CPT) * CGU;
             const float *arow = tile + (mbase + r + j * d) * S + g;
 #pragma unroll
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int n = 0; n < NTL; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bw[u][n], acc[i][n], 0, 0, 0);
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bfrag(bw, u, n), acc[i][n], 0, 0, 0);
             }
         };
         // The prefetch is UNCONDITIONAL (past the end it re-reads the last chunk): a load under a branch makes
@@ -358,7 +374,7 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
             compute(bcur, q);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < CGU; ++u)
+            for (int u = 0; u < G4; ++u)
 #pragma unroll
                 for (int n = 0; n < NTL; ++n) bcur[u][n] = bnxt[u][n];
         }
@@ -1025,6 +1041,10 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
     a.x = x; a.out = out; a.acc = acc; a.L = L;
     a.w1 = c1.wp; a.b1 = c1.bias; a.a1 = c1.act_a; a.ib1 = c1.act_ib;
     a.w2 = c2.wp; a.b2 = c2.bias; a.a2 = c2.act_a; a.ib2 = c2.act_ib;
+    if (c1.cin >= 32) {                                    // amp_pair_kernel<32 / 64, ...> streams its weights in 16-byte granules
+        if (!c1.wp4 || !c2.wp4) { set_error("amp_pair: layer pair without the 16-byte weight packing"); return BVC_EINVAL; }
+        a.w1 = c1.wp4; a.w2 = c2.wp4;
+    }
     a.divisor = divisor; a.epi = epi; a.ks = c1.ks; a.dil = c1.dil; a.tiles_per_batch = 0;
     a.bs = win ? win->in_bs : L * c1.cin;
     a.row_begin = win ? win->row_begin : 0;
