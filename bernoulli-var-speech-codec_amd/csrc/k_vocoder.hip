@@ -229,6 +229,9 @@ struct AmpArgs {
     long long t_origin;           // global time of buffer row 0 (streaming); 0 offline
 };
 
+#ifndef BVC_AMP_PINGPONG
+#define BVC_AMP_PINGPONG 1
+#endif
 #ifdef BVC_PHASE_PROBE
 __device__ unsigned long long g_phase[16];
 #define PHASE(i) do { if (threadIdx.x == 0) { unsigned long long now_ = __builtin_readcyclecounter(); atomicAdd(&g_phase[i], now_ - last_); last_ = now_; } } while (0)
@@ -367,16 +370,34 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
         // the compiler wait with vmcnt(0) before the next MFMA, i.e. for the prefetch it has just issued, or
         // sink the load next to its use.  The register copy at the end of a chunk is where the wait belongs.
         loadb(bcur, 0);
+        if constexpr (BVC_AMP_PINGPONG && C == 32) {
+            // the two register sets take turns (no copies: 16 v_mov per tap otherwise); an odd last chunk is multiplied behind the loop.
+            // (C = 64 with the waves along the columns spills in this form.)
+            int q = 0;
 #pragma unroll 1
-        for (int q = 0; q < nch; ++q) {
-            loadb(bnxt, q + 1 < nch ? q + 1 : nch - 1);
-            __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this chunk's MFMAs
-            compute(bcur, q);
-            __builtin_amdgcn_sched_barrier(0);
+            for (; q + 1 < nch; q += 2) {
+                loadb(bnxt, q + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(bcur, q);
+                __builtin_amdgcn_sched_barrier(0);
+                loadb(bcur, q + 2 < nch ? q + 2 : nch - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(bnxt, q + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q < nch) compute(bcur, q);
+        } else {
+#pragma unroll 1
+            for (int q = 0; q < nch; ++q) {
+                loadb(bnxt, q + 1 < nch ? q + 1 : nch - 1);
+                __builtin_amdgcn_sched_barrier(0);             // keep the prefetch ahead of this chunk's MFMAs
+                compute(bcur, q);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < G4; ++u)
+                for (int u = 0; u < G4; ++u)
 #pragma unroll
-                for (int n = 0; n < NTL; ++n) bcur[u][n] = bnxt[u][n];
+                    for (int n = 0; n < NTL; ++n) bcur[u][n] = bnxt[u][n];
+            }
         }
     };
 
