@@ -181,9 +181,9 @@ struct FlowArgs {
     int dbg_hot_w;                          // experiments only (BVC_FLOW_HOTW=1): every weight request hits the same blocks (wrong results)
     int MG;                                 // utterance groups (chains) per workgroup; 1 = one chain (B <= 16 * CUs / feature tiles)
     int dbg_withhold;                       // tests only: workgroup 0 returns at once
-    // decode with the folded hop (bvcodec_abi.hip: build_bvrnn): dec.6 has no activation, so phi_x.0(norm(dec.6(u))) is ONE affine map
+    // the folded hop (bvcodec_abi.hip: build_bvrnn): dec.6 has no activation, so phi_x.0(norm(dec.6(u))) is ONE affine map
     // of u = ELU(dec.4(.)) followed by the ELU: pxc = (phi_x.0.W diag(1/std) dec.6.W, phi_x.0.W ((dec.6.b - mean) / std) + phi_x.0.b).
-    // The kernel then runs dec.4 -> pxc -> phi_x.2 ... (one wide layer instead of the two narrow hops dec.6, phi_x.0), stores u for
+    // The kernel then runs dec.4 -> pxc -> phi_x.2 ... (one wide layer instead of the two narrow hops dec.6, phi_x.0); decode stores u for
     // all frames in `keep` (B,T,H), and dec.6 itself - the decoder's output - is one batched GEMM over `keep` behind the launch.
     FlowLin pxc;                            // w == null: the layers as the reference lists them
     float *keep;

@@ -978,8 +978,8 @@ __device__ __forceinline__ void flow_gru_chains(FlowCtx &c, int hopid, int hb, c
 // layer chain by chain with the same weight registers; by the time it returns to a chain for the next layer, that chain's
 // inputs - produced by the other workgroups in the same order - have long arrived, so the hand-off latency of one chain lies
 // under the products of the others.  Batches of more than 16 * (CUs / feature tiles) utterances (64 at h_dim 1024) run this way.
-// FOLD (decode): 1 / 0: the folded hop (FlowArgs::pxc) is / is not compiled in; -1: both, chosen at run time.  (The interleaved-chain
-// decode kernel with both programs in it spills 7 VGPRs: it is instantiated once per program.)
+// FOLD: 1 / 0: the folded hop (FlowArgs::pxc) is / is not compiled in; -1: both, chosen at run time.  (The interleaved-chain
+// kernels with both programs in them spill: they are instantiated once per program.)
 template <int PERH, bool ENCODE, bool FILL, int NW = 8, bool MULTI = false, int FOLD = -1>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) void bvrnn_flow_kernel(const FlowArgs *a0) {
     static_assert(!(MULTI && FILL), "the filler quanta are per chain: not built for interleaved chains");
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
         // h half of dec.0, the three gates of W_ih[:, H:] phi_z.  The GRU layer then only has phi_x(d_t)'s third left.
         constexpr int G0 = FILL ? 0 : -2, G1 = FILL ? 1 : -2, G2 = FILL ? 2 : -2, GP = FILL ? -1 : -2;
         const FlowFill f_hh = {a.w_hh, hb, hb, hsrc}, f_d0 = {a.dec0h.w, a.dec0h.wnb, hb, hsrc}, f_iz = {a.w_ihz, 2 * hb, hb, zsrc};
-        const bool folded = !ENCODE && (FOLD < 0 ? a.pxc.w != nullptr : FOLD == 1);     // (uniform) decode: dec.6 -> norm -> phi_x.0 folded into one layer (FlowArgs::pxc)
+        const bool folded = FOLD < 0 ? a.pxc.w != nullptr : FOLD == 1;      // (uniform) dec.6 -> norm -> phi_x.0 folded into one layer (FlowArgs::pxc)
         if constexpr (!MULTI) {
             if (ENCODE) {
                 //         PER   epilogue  two    add    pre_in pre_out       rearm  filler
@@ -1076,8 +1076,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                     flow_layer<PERH, FE_ELU, true, false, true, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb, gq);
                 }
                 flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, gq, zero4, f_iz, &c.fgi[1]);
-                flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, gq, zero4, f_iz, &c.fgi[2]);
-                flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb, gq);
+                if (folded) {
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.pxc), wb, gq, zero4, f_iz, &c.fgi[2]);
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 11, L(a.pxc), FB_D3, L(a.pxc), 0, hb, hb, FB_G1, wb, L(a.px1), wa, gq);
+                } else {
+                    flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, gq, zero4, f_iz, &c.fgi[2]);
+                    flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb, gq);
+                }
             } else {
                 flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, gq, zero4, f_hh, &c.fgh[0]);
                 flow_layer<PERH, FE_ELU, false, false, true, true, PERH, true, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, gq, zero4, f_hh, &c.fgh[1]);
@@ -1089,7 +1094,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                     flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb, gq);
                 }
             }
-            if (ENCODE || !folded)
+            if (!folded)
                 flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa, gq);
             flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb, gq);
             flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, -2, NW, GFAST>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa, gq);
@@ -1115,7 +1120,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                     flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW, true>(c, 7, d0, FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb, mt0, nch, T, L(a.dec0h), FB_H);
                 }
                 flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 8, L(a.dec1), FB_D1, hb, hb, FB_D2, wb, L(a.dec2), wa, mt0, nch, T);
-                flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.dec2), wb, mt0, nch, T);
+                if (folded) {
+                    flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.pxc), wb, mt0, nch, T);
+                    flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 11, L(a.pxc), FB_D3, hb, hb, FB_G1, wb, L(a.px1), wa, mt0, nch, T);
+                } else {
+                    flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.dec2), wb, mt0, nch, T);
+                }
             } else {
                 flow_layer_chains<PERH, FE_ELU, true, true, true, PERH, false, NW>(c, 7, L(a.dec0h), FB_H, hb, hb, FB_D1, wa, L(a.dec1), wb, mt0, nch, T);
                 flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, true, NW>(c, 8, L(a.dec1), FB_D1, hb, hb, FB_D2, wb, L(a.dec2), wa, mt0, nch, T);
@@ -1126,7 +1136,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                     flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.dec2), wb, mt0, nch, T);
                 }
             }
-            if (ENCODE || !folded) {
+            if (!folded) {
                 flow_layer_chains<PERH, FE_MEL, false, false, false, PERH, false, NW>(c, 10, L(a.dec3), FB_D3, hb, xb, FB_DN, wa, L(a.dec3), wb, mt0, nch, T);
                 FLOW_EACH_CHAIN(flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa, gq));
             }
@@ -1189,7 +1199,8 @@ int launch_flow_census(unsigned *ctr, int grid, unsigned spin_limit, hipStream_t
 int flow_kernels_init() {
     int rc;
     BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(flow_census_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_FILL));
-    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<8, true, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_MULTI));
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<8, true, false, 8, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_MULTI));
+    BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<8, true, false, 8, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_MULTI));
     BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<8, false, false, 8, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_MULTI));
     BVC_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(bvrnn_flow_kernel<8, false, false, 8, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOW_LDS_MULTI));
 
@@ -1235,7 +1246,8 @@ int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, bool
     if (a.MG > 1) {                                        // interleaved chains: more utterance groups than workgroup slots per feature tile
         if (perh != 8) { set_error("launch_flow: interleaved chains are built for h_dim 1024 only"); return BVC_EINVAL; }
         const int grid_m = ((a.NTG + 7) / 8) * 8 * ((a.MT + a.MG - 1) / a.MG);
-        if (encode) hipLaunchKernelGGL((bvrnn_flow_kernel<8, true, false, 8, true>), dim3(grid_m), dim3(512), FLOW_LDS_MULTI, s, d_a);
+        if (encode && a.pxc.w) hipLaunchKernelGGL((bvrnn_flow_kernel<8, true, false, 8, true, 1>), dim3(grid_m), dim3(512), FLOW_LDS_MULTI, s, d_a);
+        else if (encode) hipLaunchKernelGGL((bvrnn_flow_kernel<8, true, false, 8, true, 0>), dim3(grid_m), dim3(512), FLOW_LDS_MULTI, s, d_a);
         else if (a.pxc.w) hipLaunchKernelGGL((bvrnn_flow_kernel<8, false, false, 8, true, 1>), dim3(grid_m), dim3(512), FLOW_LDS_MULTI, s, d_a);
         else        hipLaunchKernelGGL((bvrnn_flow_kernel<8, false, false, 8, true, 0>), dim3(grid_m), dim3(512), FLOW_LDS_MULTI, s, d_a);
         BVC_HIP_TRY(hipGetLastError());

@@ -118,11 +118,15 @@ void bvc_model_destroy(bvc_model *m);
  *                 non-linearity between them (bvrnn.py:80, :226) - as ONE affine map of u (folded in float64 at model creation):
  *                 one wide layer instead of two narrow hops per frame; dec.6(u), the decoder's output, is then one batched GEMM
  *                 over the kept u of all frames.  mel^ / h_T agree with the layer-by-layer program to rounding (2e-5 / 5e-6 in
- *                 the tests); 0 = the layers as the reference lists them.  Encode never folds.
+ *                 the tests); 0 = the layers as the reference lists them.
+ *   "encode_fold": 1 (default) = the same fold in the persistent ENCODE kernel (dec.6's output is not needed there).  The
+ *                 folded layer feeds the next state and so the next codes: the same function with another rounding, like
+ *                 another order of summation - the goldens and the full-size parity runs give the same bits either way
+ *                 (tests/test_gpu_robustness.py compares both settings); 0 = the layers as the reference lists them.
  *   "flow_spin_limit" (polls before a wait inside the persistent kernel gives up; default 4,000,000, more than a second),
  *   "flow_debug_withhold" (1: workgroup 0 of every persistent launch does nothing, so its consumers time out),
  *   "flow_debug_nofill" (1: the plain layer program without filler quanta): test switches.
- * bvc_model_get_option reads "recurrence", "decode_fold", "flow_resident" (1: the census found a full persistent grid co-resident),
+ * bvc_model_get_option reads "recurrence", "decode_fold", "encode_fold", "flow_resident" (1: the census found a full persistent grid co-resident),
  * "flow_supported" (1: h_dim / z_dim / num_mels are laid out for the persistent kernel), "compute_units". */
 int bvc_model_set_option(bvc_model *m, const char *name, int32_t value);
 int bvc_model_get_option(const bvc_model *m, const char *name, int32_t *value);

@@ -99,6 +99,42 @@ def test_folded_decode_hop_vs_layer_by_layer_program_and_oracle(h_dim, B):
         assert (hT[0, pick].cpu() - d["h_last"]).abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("h_dim,B", [(1024, 64), (1024, 130), (256, 20)])
+def test_folded_encode_hop_vs_layer_by_layer_program_and_oracle(h_dim, B):
+    """The same fold in the persistent ENCODE kernel (`encode_fold`, default on): the folded layer feeds the next state, hence the
+    next codes.  Codes / probabilities / states against the layer-by-layer program of the same kernel and against
+    oracle.bvrnn.encode: a bit may differ only where the oracle's own probability sits within rounding noise of the tie."""
+    from gpu_common import make_model
+    from oracle import bvrnn as obv
+    model, conf, vr, _ = make_model(True, h_dim)
+    eng = model.engine()
+    assert eng.get_option("encode_fold") == 1
+    rng = np.random.default_rng(11 * h_dim + B)
+    T = 40
+    y = torch.from_numpy((-4.0 + 1.6 * rng.standard_normal((B, T, 80))).astype(np.float32))
+    bits = torch.from_numpy(rng.integers(8, 65, size=(B, T)).astype(np.float32))
+    h0 = torch.from_numpy((0.2 * rng.standard_normal((B, h_dim))).astype(np.float32))
+    try:
+        model.set_recurrence("persistent")
+        c1, h1, p1 = model.bvrnn.encode(y.to(DEV), bits.to(DEV), h0.unsqueeze(0).to(DEV), return_prob=True)
+        eng.set_option("encode_fold", 0)
+        c0, h0_all, p0 = model.bvrnn.encode(y.to(DEV), bits.to(DEV), h0.unsqueeze(0).to(DEV), return_prob=True)
+        torch.cuda.synchronize()
+        model.check_status()
+    finally:
+        eng.set_option("encode_fold", 1)
+        model.set_recurrence("auto")
+    pick = [0, B // 2, B - 1]
+    r = obv.encode(vr, y[pick], bits[pick], h0[pick])
+    for codes, all_h, prob in ((c1, h1, p1), (c0, h0_all, p0)):
+        n_diff = _ties_only(codes[pick].cpu(), r["codes"], r["prob"])
+        if n_diff == 0:
+            assert (prob[pick].cpu() - r["prob"]).abs().max().item() < 2e-6
+            assert (all_h[pick].cpu() - r["all_h"]).abs().max().item() < 5e-6
+    if torch.equal(c1, c0):
+        assert (p1 - p0).abs().max().item() < 2e-6 and (h1 - h0_all).abs().max().item() < 5e-6
+
+
 # --------------------------------------------------------------------------- edge shapes
 def test_single_frame_and_zero_length():
     """T = 1 through every stage (the facade cannot produce it: reflect padding needs L > 512, i.e. two frames) and
