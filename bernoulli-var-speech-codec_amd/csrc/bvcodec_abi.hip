@@ -607,6 +607,7 @@ enum { OP_KERNEL = 0, OP_RECORD = 1, OP_WAIT = 2 };
 enum { BR_MAIN = 0, BR_SIDE = 1 };
 struct StepNode { int op; int branch; int event; GemmParams p; int epi; };
 enum { STEP_ENCODE = 0, STEP_DECODE = 1, STEP_DECODE_PRE = 2 };   // _PRE: phi_z halves of dec.0 / GRU arrive pre-computed
+enum { STEP_KIND_MASK = 0xF, STEP_FOLD = 0x10 };                  // | STEP_FOLD: the folded hop (step_fold below)
 constexpr int64_t SMALL_T_FRAMES = 4;          // up to this many frames per call the all-frame MLPs run frame by frame on the recurrent-layer kernel
 constexpr int64_t PRECOMP_MIN_FRAMES = 16;     // below this (streaming hops) the two extra batched GEMMs cost more than they save
 enum { EV_START = 0, EV_DEC0H = 1, EV_PZ = 2, EV_GATES = 3, EV_COUNT = 4 };
@@ -620,7 +621,9 @@ enum { EV_START = 0, EV_DEC0H = 1, EV_PZ = 2, EV_GATES = 3, EV_COUNT = 4 };
 // Side branch: the halves of the split dot products that do not depend on the current frame's chain -
 // dec.0[:, H:] h, W_hh h + b_hh, W_ih[:, H:] phi_z + b_ih - run concurrently with the chain (which is
 // latency-bound), so the GRU kernel on the critical path only streams W_ih[:, :H].
-std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, int kind) {
+std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, int kind_and_fold) {
+    const int kind = kind_and_fold & STEP_KIND_MASK;
+    const bool fold = (kind_and_fold & STEP_FOLD) != 0;       // dec.6 -> norm -> phi_x.0 as one layer (bvc_model::px0_dec3)
     const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
     std::vector<StepNode> plan;
     const long long MH = (long long)((B + 15) / 16) * 16 * H;
@@ -702,13 +705,20 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
     }
     (void)n_dec0;
     K(BR_MAIN, lin_params(m->dec[1], S(d1, H), B, S(d2, H)), EPI_ELU);
-    K(BR_MAIN, lin_params(m->dec[2], S(d2, H), B, S(d3, H)), EPI_ELU);
-    {
+    if (fold) {
+        // one launch less per frame: u = ELU(dec.4) (decode: also kept for all frames - dec.6(u), the decoder's output, is one batched
+        // GEMM behind the recurrence), then phi_x.0(norm(dec.6(u))) as the one folded layer
+        GemmParams p = lin_params(m->dec[2], S(d2, H), B, S(d3, H));
+        if (kind != STEP_ENCODE) p.y2 = dp_frame(DS_KEEP, H);
+        K(BR_MAIN, p, EPI_ELU);
+        K(BR_MAIN, lin_params(m->px0_dec3, S(d3, H), B, S(g1, H)), EPI_ELU);
+    } else {
+        K(BR_MAIN, lin_params(m->dec[2], S(d2, H), B, S(d3, H)), EPI_ELU);
         GemmParams p = lin_params(m->dec[3], S(d3, H), B, kind != STEP_ENCODE ? dp_frame(DS_MEL, X) : dp_null());
         p.y2 = S(dn, X); p.mean = m->mean_mel; p.stdv = m->std_mel;
         K(BR_MAIN, p, EPI_MEL);
+        K(BR_MAIN, lin_params(m->phi_x[0], S(dn, X), B, S(g1, H)), EPI_ELU);
     }
-    K(BR_MAIN, lin_params(m->phi_x[0], S(dn, X), B, S(g1, H)), EPI_ELU);
     K(BR_MAIN, lin_params(m->phi_x[1], S(g1, H), B, S(g2, H)), EPI_ELU);
     K(BR_MAIN, lin_params(m->phi_x[2], S(g2, H), B, S(g3, H)), EPI_ELU);
     {
@@ -844,6 +854,14 @@ int get_step_graph(const bvc_model *m, const Workspace &w, void *ws_base, int B,
     m->graphs.push_front(sg);
     *out = &m->graphs.front();
     return BVC_OK;
+}
+
+// Does the launch-per-layer schedule of this call fold the hop?  Encode: whenever the model does (one launch less per frame, ticks
+// included).  Decode: not on streaming hops - their one or two frames would trade T small launches for one batched GEMM.
+int step_fold(const bvc_model *m, bool encode, int64_t T) {
+    if (!m->px0_dec3.wp || m->side_branch) return 0;
+    if (encode) return m->encode_fold ? STEP_FOLD : 0;
+    return (m->decode_fold && T > SMALL_T_FRAMES && !g_stream_tick) ? STEP_FOLD : 0;
 }
 
 int run_recurrence(const bvc_model *m, const Workspace &w, void *ws_base, int B, int64_t T, int kind, hipStream_t s) {
@@ -1203,8 +1221,9 @@ int run_encode_body(const bvc_model *m, const Workspace &w, void *ws_base, const
     d.p[DS_PX] = w.pxA; d.p[DS_CODES] = d_codes; d.p[DS_BITS] = const_cast<float *>(d_bits);
     d.p[DS_PROB] = d_prob; d.p[DS_ALLH] = d_all_h;
     d.T = T;
-    if ((rc = begin_call(m, w, d, count_kernels(build_step(m, w, B, STEP_ENCODE)), s))) return rc;
-    if ((rc = run_recurrence(m, w, ws_base, B, T, STEP_ENCODE, s))) return rc;
+    const int kind_e = STEP_ENCODE | step_fold(m, true, T);
+    if ((rc = begin_call(m, w, d, count_kernels(build_step(m, w, B, kind_e)), s))) return rc;
+    if ((rc = run_recurrence(m, w, ws_base, B, T, kind_e, s))) return rc;
     if (d_hT && (rc = read_state(w, B, H, T, d_hT, s))) return rc;
     return BVC_OK;
 }
@@ -1246,9 +1265,13 @@ int run_decode_body(const bvc_model *m, const Workspace &w, void *ws_base, const
     if ((rc = init_state(w, d_h0, B, H, s))) return rc;
     d.p[DS_MEL] = d_mel;
     d.T = T;
-    if ((rc = begin_call(m, w, d, count_kernels(build_step(m, w, B, kind)), s))) return rc;
-    if ((rc = run_recurrence(m, w, ws_base, B, T, kind, s))) return rc;
+    const int kind_d = kind | step_fold(m, false, T);
+    if (kind_d & STEP_FOLD) d.p[DS_KEEP] = w.pxB;       // (idle once the batched phi_z layers are through)
+    if ((rc = begin_call(m, w, d, count_kernels(build_step(m, w, B, kind_d)), s))) return rc;
+    if ((rc = run_recurrence(m, w, ws_base, B, T, kind_d, s))) return rc;
     if (d_hT && (rc = read_state(w, B, H, T, d_hT, s))) return rc;
+    if ((kind_d & STEP_FOLD) && d_mel &&                // the decoder's output dec.6(u_t), all frames at once (bvrnn.py:224-225)
+        (rc = launch_gemm_batched(w.pxB, H, m->dec[3].w, H, m->dec[3].b, (int)((long long)B * T), m->cfg.num_mels, H, 0, d_mel, m->cfg.num_mels, s))) return rc;
     return BVC_OK;
 }
 

@@ -258,6 +258,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             }
             if (epi == EPI_ELU) o = elu1(o);
             store_out(y, m, n, o);
+            if (p.y2.meta & 15) {                                             // a second copy (the folded hop keeps ELU(dec.4) of every frame)
+                const Resolved y2 = resolve(p.y2, dsc, mt16, p.tstep);
+                if (y2.ok) store_out(y2, m, n, o);
+            }
         } else if (epi == EPI_SIGMOID) {
             store_out(y, m, n, sigmoid1(v[0]));
         } else if (epi == EPI_CODE) {
