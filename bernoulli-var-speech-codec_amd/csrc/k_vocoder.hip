@@ -1089,17 +1089,11 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
         // tile shapes from a measured sweep (tools/voc_stage_times.py): MT = 16-row tiles per wave, OCC = workgroups per CU the
         // register budget is set for, ALIAS = the S2 tile re-uses the LDS of the S1 tile (one more barrier, half the LDS)
         case 64: {
-            static const int v = getenv("BVC_AMP64") ? atoi(getenv("BVC_AMP64")) : 8;
-            if (v == 0) return launch_amp_t<64, 2, 2, true>(a, B, s);          // waves along the rows: 3.12 -> 2.62 ms per step vs <64,1,2,false>
-            if (v == 24) return launch_amp_t<64, 4, 2, true, 2>(a, B, s);      // two column groups x two row groups
-            return launch_amp_t<64, 8, 2, true, 4>(a, B, s);                   // waves along the columns: 2.63 -> 2.36
+            static const bool rows = getenv("BVC_AMP64") && atoi(getenv("BVC_AMP64")) == 0;       // A/B: the waves along the rows (2.63 ms per step for the stage)
+            if (rows) return launch_amp_t<64, 2, 2, true>(a, B, s);
+            return launch_amp_t<64, 8, 2, true, 4>(a, B, s);       // waves along the columns: 2.33 (two column groups x two row groups: 2.60)
         }
-        case 32: {
-            static const int v = getenv("BVC_AMP32") ? atoi(getenv("BVC_AMP32")) : 0;
-            if (v == 8) return launch_amp_t<32, 8, 3, true, 2>(a, B, s);
-            if (v == 4) return launch_amp_t<32, 4, 3, true, 2>(a, B, s);
-            return launch_amp_t<32, 4, 3, true>(a, B, s);      // 4.96 -> 4.83
-        }
+        case 32: return launch_amp_t<32, 4, 3, true>(a, B, s);     // (waves along the columns, CS = 2 with 4 or 8 row tiles: 4.64 / 4.41 against 4.48)
         case 16: {
             if (g_amp16_enabled && !win) {                  // offline sweep: the persistent C = 16 kernel
                 // four row tiles per wave (256 rows per workgroup): 2.82 (generic kernel) -> 2.62 ms per step for the stage; two tiles 2.82,
