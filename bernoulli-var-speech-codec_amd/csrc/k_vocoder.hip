@@ -283,19 +283,25 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     // SnakeBeta is evaluated (one exposed memory round trip per workgroup instead of one per row group).
     {
         constexpr int NLD = ((TR + 10 * 5) * C4 + 255) / 256;       // ks <= 11, dil <= 5
+        // The loads are UNCONDITIONAL (rows outside the signal read a clamped row and are zeroed afterwards): a load under a branch
+        // made hipcc wait `vmcnt(0)` behind every other one - five exposed round trips per tile at C = 32 instead of one.
         f32x4 v[NLD];
         const int total = rows1 * C4;
+        unsigned okmask = 0u;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + i * 256;
             const int row = idx / C4, c4 = idx - row * C4;
             const long long tg = tbase - halo1 + row;
-            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (idx < total && tg >= 0 && tg < a.L) v[i] = *reinterpret_cast<const f32x4 *>(xb + tg * C + c4 * 4);
+            const bool ok = idx < total && tg >= 0 && tg < a.L;
+            const long long tgc = tg < 0 ? 0 : (tg < a.L ? tg : a.L - 1);
+            v[i] = *reinterpret_cast<const f32x4 *>(xb + tgc * C + c4 * 4);
+            okmask |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + i * 256;
+            if (!((okmask >> i) & 1u)) v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (idx < total) {
                 const int row = idx / C4, c4 = idx - row * C4;
                 const f32x4 aa = *reinterpret_cast<const f32x4 *>(a.a1 + c4 * 4);
@@ -496,12 +502,13 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     const long long rows_left = a.L - t0;
     const int nvalid4 = (int)(rows_left < TT ? rows_left : TT) * C4;
     f32x4 resq[NLD3], accq[NLD3];
+    const bool with_acc = a.epi >= CE_RES_ACC;             // (uniform)
 #pragma unroll
-    for (int i = 0; i < NLD3; ++i) {
+    for (int i = 0; i < NLD3; ++i) {                       // unconditional, clamped: items past the tile's valid rows are never stored
         const int idx = tid + i * 256;
-        const bool ok = idx < nvalid4;
-        resq[i] = ok ? reinterpret_cast<const f32x4 *>(a.x + ob)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
-        accq[i] = (ok && a.epi >= CE_RES_ACC) ? reinterpret_cast<const f32x4 *>(a.acc + ob)[idx] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int idc = idx < nvalid4 ? idx : 0;
+        resq[i] = reinterpret_cast<const f32x4 *>(a.x + ob)[idc];
+        accq[i] = with_acc ? reinterpret_cast<const f32x4 *>(a.acc + ob)[idc] : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     PHASE(3);
     conv(t2, 1, a.w2);
