@@ -65,6 +65,42 @@ def test_persistent_kernel_families_vs_oracle(h_dim, B, nofill):
         model.set_recurrence("auto")
 
 
+def test_folded_hop_on_the_launch_per_layer_schedule():
+    """The launch-per-layer schedule folds the hop as well (one launch less per frame; decode keeps ELU(dec.4) of every frame
+    and computes dec.6 as a batched GEMM behind the recurrence): with and without the fold, against each other and the oracle."""
+    from gpu_common import make_model
+    from oracle import bvrnn as obv
+    model, conf, vr, _ = make_model(True, 1024)
+    eng = model.engine()
+    rng = np.random.default_rng(99)
+    B, T = 24, 30
+    y = torch.from_numpy((-4.0 + 1.6 * rng.standard_normal((B, T, 80))).astype(np.float32))
+    bits = torch.from_numpy(rng.integers(8, 65, size=(B, T)).astype(np.float32))
+    h0 = torch.from_numpy((0.2 * rng.standard_normal((B, 1024))).astype(np.float32))
+    r = obv.encode(vr, y, bits, h0)
+    d = obv.decode(vr, r["codes"], h0)
+    out = {}
+    try:
+        model.set_recurrence("layers")
+        for fold in (1, 0):
+            eng.set_option("encode_fold", fold)
+            eng.set_option("decode_fold", fold)
+            codes, all_h, prob = model.bvrnn.encode(y.to(DEV), bits.to(DEV), h0.unsqueeze(0).to(DEV), return_prob=True)
+            mel, hT = model.bvrnn.decode(r["codes"].to(DEV), h0.unsqueeze(0).to(DEV))
+            out[fold] = (codes.cpu(), prob.cpu(), mel.cpu(), hT.cpu())
+    finally:
+        eng.set_option("encode_fold", 1)
+        eng.set_option("decode_fold", 1)
+        model.set_recurrence("auto")
+    for fold in (1, 0):
+        codes, prob, mel, hT = out[fold]
+        if _ties_only(codes, r["codes"], r["prob"]) == 0:
+            assert (prob - r["prob"]).abs().max().item() < 2e-6
+        assert (mel - d["mel"]).abs().max().item() < 5e-5
+        assert (hT[0] - d["h_last"]).abs().max().item() < 5e-6
+    assert (out[1][2] - out[0][2]).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("h_dim,B", [(1024, 64), (1024, 130), (256, 20)])
 def test_folded_decode_hop_vs_layer_by_layer_program_and_oracle(h_dim, B):
     """bvrnn.py:80 / :226: dec.6 has no activation, so phi_x.0(norm(dec.6(u))) is one affine map of u.  The persistent DECODE kernel
