@@ -411,23 +411,18 @@ __device__ __forceinline__ void flow_publish(const FlowCtx &c, int hopid, const 
 #pragma unroll
     for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4 *>(r + (w * 64 + lane) * 4);
     v += bias4;
-    f32x4 o;
+    f32x4 o, pr = {0.f, 0.f, 0.f, 0.f};
     if (EPI == FE_ELU || EPI == FE_ELU_KEEP) {
         if (ADD) v += add4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = elu1(v[j]);
     } else if (EPI == FE_CODE) {                       // bvrnn.py:189-194
-        f32x4 pr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             pr[j] = sigmoid1(v[j]);
             float z = rintf(pr[j]);                    // round half to even (torch.round)
             if (a.var_bit) z = (bitsv > (float)(n0 + j)) ? z : (z != z ? z : 0.5f);    // z*m + 0.5*(1-m): NaN * 0 is NaN (bvrnn.py:193-194)
             o[j] = z;
-        }
-        if (c.rowok) {
-            *reinterpret_cast<f32x4 *>(a.codes + c.fr * (ntiles * 16) + n0) = o;
-            if (a.prob) *reinterpret_cast<f32x4 *>(a.prob + c.fr * (ntiles * 16) + n0) = pr;
         }
     } else {                                           // FE_MEL, bvrnn.py:202-204
         if (a.mel && c.rowok) *reinterpret_cast<f32x4 *>(a.mel + c.fr * (ntiles * 16) + n0) = v;
@@ -444,6 +439,10 @@ __device__ __forceinline__ void flow_publish(const FlowCtx &c, int hopid, const 
     // consumed h(t), i.e. had all finished frame t-1: nobody reads h(t-1) any more (same tile shape as this layer's).
     if (REARM_H) __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, (unsigned)(FB_H * 2 + (c.par ^ 1u)) * c.sb + ytile, 0, AUX_SC1);
     if (EPI == FE_ELU_KEEP && c.rowok) *reinterpret_cast<f32x4 *>(a.keep + c.fr * (ntiles * 16) + n0) = o;     // (behind the hand-off stores)
+    if (EPI == FE_CODE && c.rowok) {                    // the call's outputs: behind the hand-off stores as well (-0.06 ms per step)
+        *reinterpret_cast<f32x4 *>(a.codes + c.fr * (ntiles * 16) + n0) = o;
+        if (a.prob) *reinterpret_cast<f32x4 *>(a.prob + c.fr * (ntiles * 16) + n0) = pr;
+    }
     __builtin_amdgcn_s_setprio(0);
     flow_stamp(c, hopid, 1);
 }
