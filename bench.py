@@ -295,6 +295,27 @@ def leg_target_workload(conf, model, device, B, bitrate, with_parity, steps=5):
     return out
 
 
+def leg_large_batch(conf, model, device, bitrate, with_parity, B=256, steps=3):
+    """Not a BASELINE config: 256 x 5 s in ONE call, the persistent recurrence on interleaved chains (four utterance groups per
+    workgroup) - what a caller gets who can batch more than 64 utterances."""
+    L = int(FS * SECONDS)
+    x = synth.synthetic_speech(B, L, seed=2000, kind="noise").to(device)
+
+    def step():
+        codes = model.encode(x, bitrate)
+        return codes, model.decode(codes, L)
+    step()
+    dt, (codes, wav) = time_steps(step, steps, device)
+    model.check_status()
+    out = {"workload": f"batch {B} x {SECONDS:g} s in one call @ {bitrate:g} bit/s, full encode -> BigVGAN decode",
+           "value": round(B * SECONDS * steps / dt, 2), "unit": "audio-seconds/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps}
+    if with_parity:                # the last utterance: last chain of the last workgroup slot
+        out["parity"] = dict(spot_check(conf, model, x[B - 1:], codes[B - 1:], wav[B - 1:], L, bitrate), utterances_checked=[B - 1])
+    del x, codes, wav
+    torch.cuda.empty_cache()
+    return out
+
+
 def leg_encode_only(conf, model, device, x, bitrate, ref_codes, steps=5):
     """BASELINE configs[2]: STFT/mel + BVRNN.encode, no vocoder; `recurrence`: the persistent encode launch alone."""
     B, L = x.shape
@@ -371,7 +392,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the target_workload / encode_only / streaming legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the target_workload / encode_only / streaming / large_batch legs")
     a = ap.parse_args()
 
     # RCCL prints a version banner on STDOUT when its communicator is created; this program's stdout is one JSON line, so
@@ -581,6 +602,8 @@ def main():
         note("encode_only done")
         out["streaming"] = leg_streaming(conf, model, device, a.bitrate, with_par)
         note("streaming done")
+        out["large_batch"] = leg_large_batch(conf, model, device, a.bitrate, with_par)
+        note("large_batch done")
     if rank == 0 and not (a.no_parity and (a.no_cpu_baseline or world > 1)):
         leg = oracle_leg(conf, model, x, codes, wav, L, a.bitrate, a.mode, with_baseline=(world == 1 and not a.no_cpu_baseline))
         if not a.no_parity:
