@@ -1,0 +1,65 @@
+// Do MFMA and ordinary vector instructions of DIFFERENT waves overlap on a SIMD of gfx950?
+// A workgroup of 8 waves (two per SIMD: waves w and w + 4 share SIMD w % 4).  Modes:
+//   0: waves 0-3 run an MFMA loop, waves 4-7 return at once            -> T_mfma
+//   1: waves 4-7 run a packed-fp32 FMA loop, waves 0-3 return at once  -> T_valu
+//   2: waves 0-3 MFMA loop, waves 4-7 FMA loop                         -> max(T_mfma, T_valu) if they overlap, the sum if not
+//   3: all eight waves run half the MFMA loop and half the FMA loop one after the other (what the vocoder's kernels do)
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/mfma_valu_overlap tools/mfma_valu_overlap.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void mfma_loop(int iters, float seed, float *sink) {
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (f32x4){seed, seed, seed, seed};
+    const float a = seed + 1.0f, b = seed * 0.5f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+    if (s == 12345.678f) *sink = s;
+}
+__device__ __forceinline__ void valu_loop(int iters, float seed, float *sink) {
+    f32x2 v[8];
+    for (int i = 0; i < 8; ++i) v[i] = (f32x2){seed + i, seed - i};
+    const f32x2 m = {1.0000001f, 0.9999999f}, c = {1e-7f, -1e-7f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_elementwise_fma(v[i], m, c);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += v[i][0] + v[i][1];
+    if (s == 12345.678f) *sink = s;
+}
+
+__global__ __launch_bounds__(512) void k(int mode, int n_mfma, int n_valu, float seed, float *sink) {
+    const int wave = threadIdx.x >> 6;
+    if (mode == 0) { if (wave < 4) mfma_loop(n_mfma, seed, sink); }
+    else if (mode == 1) { if (wave >= 4) valu_loop(n_valu, seed, sink); }
+    else if (mode == 2) { if (wave < 4) mfma_loop(n_mfma, seed, sink); else valu_loop(n_valu, seed, sink); }
+    else { mfma_loop(n_mfma / 2, seed, sink); valu_loop(n_valu / 2, seed, sink); }
+}
+
+int main(int argc, char **argv) {
+    const int n_mfma = argc > 1 ? atoi(argv[1]) : 20000;       // x 8 MFMAs of 32 clocks
+    const int n_valu = argc > 2 ? atoi(argv[2]) : 80000;       // x 8 packed FMAs
+    float *sink;
+    hipMalloc(&sink, 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 2; ++rep)
+        for (int mode = 0; mode < 4; ++mode) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, mode, n_mfma, n_valu, 0.001f, sink);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (rep) printf("mode %d: %.3f ms  (%d x 8 MFMA 16x16x4 f32 per wave, %d x 8 v_pk_fma_f32 per wave; 256 workgroups x 8 waves)\n", mode, ms, mode == 1 ? 0 : (mode == 3 ? n_mfma / 2 : n_mfma), mode == 0 ? 0 : (mode == 3 ? n_valu / 2 : n_valu));
+        }
+    return 0;
+}
