@@ -4,6 +4,8 @@
 //   1: waves 4-7 run a packed-fp32 FMA loop, waves 0-3 return at once  -> T_valu
 //   2: waves 0-3 MFMA loop, waves 4-7 FMA loop                         -> max(T_mfma, T_valu) if they overlap, the sum if not
 //   3: all eight waves run half the MFMA loop and half the FMA loop one after the other (what the vocoder's kernels do)
+//   4 / 5: waves 4-7 only: the flops of mode 1 as ordinary v_fma_f32 (16 chains) / as v_pk_fma_f32 on 16 chains
+//   6 / 7: all eight waves, half the work each: ordinary / packed FMAs with two waves per SIMD
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/mfma_valu_overlap tools/mfma_valu_overlap.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -36,12 +38,43 @@ __device__ __forceinline__ void valu_loop(int iters, float seed, float *sink) {
     if (s == 12345.678f) *sink = s;
 }
 
+// the same flops as valu_loop with ordinary (one float per lane) FMAs: 16 independent chains
+__device__ __forceinline__ void scalar_loop(int iters, float seed, float *sink) {
+    float v[16];
+    for (int i = 0; i < 16; ++i) v[i] = seed + i;
+    const float m = 1.0000001f, c = 1e-7f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(v[i], m, c);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += v[i];
+    if (s == 12345.678f) *sink = s;
+}
+// packed FMAs on 16 independent chains (more instruction-level parallelism than valu_loop's 8)
+__device__ __forceinline__ void valu16_loop(int iters, float seed, float *sink) {
+    f32x2 v[16];
+    for (int i = 0; i < 16; ++i) v[i] = (f32x2){seed + i, seed - i};
+    const f32x2 m = {1.0000001f, 0.9999999f}, c = {1e-7f, -1e-7f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_elementwise_fma(v[i], m, c);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += v[i][0] + v[i][1];
+    if (s == 12345.678f) *sink = s;
+}
+
 __global__ __launch_bounds__(512) void k(int mode, int n_mfma, int n_valu, float seed, float *sink) {
     const int wave = threadIdx.x >> 6;
     if (mode == 0) { if (wave < 4) mfma_loop(n_mfma, seed, sink); }
     else if (mode == 1) { if (wave >= 4) valu_loop(n_valu, seed, sink); }
     else if (mode == 2) { if (wave < 4) mfma_loop(n_mfma, seed, sink); else valu_loop(n_valu, seed, sink); }
-    else { mfma_loop(n_mfma / 2, seed, sink); valu_loop(n_valu / 2, seed, sink); }
+    else if (mode == 3) { mfma_loop(n_mfma / 2, seed, sink); valu_loop(n_valu / 2, seed, sink); }
+    else if (mode == 4) { if (wave >= 4) scalar_loop(n_valu, seed, sink); }           // 16 v_fma_f32 per trip = the flops of 8 v_pk_fma_f32
+    else if (mode == 5) { if (wave >= 4) valu16_loop(n_valu / 2, seed, sink); }       // 16 v_pk_fma_f32 per trip, half the trips
+    else if (mode == 6) { scalar_loop(n_valu / 2, seed, sink); }                      // two waves per SIMD, ordinary FMAs
+    else { valu16_loop(n_valu / 4, seed, sink); }                                     // two waves per SIMD, packed FMAs
 }
 
 int main(int argc, char **argv) {
@@ -52,14 +85,16 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 0; mode < 4; ++mode) {
+        for (int mode = 0; mode < 8; ++mode) {
             hipEventRecord(e0);
             hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, mode, n_mfma, n_valu, 0.001f, sink);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms = 0.f;
             hipEventElapsedTime(&ms, e0, e1);
-            if (rep) printf("mode %d: %.3f ms  (%d x 8 MFMA 16x16x4 f32 per wave, %d x 8 v_pk_fma_f32 per wave; 256 workgroups x 8 waves)\n", mode, ms, mode == 1 ? 0 : (mode == 3 ? n_mfma / 2 : n_mfma), mode == 0 ? 0 : (mode == 3 ? n_valu / 2 : n_valu));
+            static const char *what[8] = {"waves 0-3: MFMA loop", "waves 4-7: v_pk_fma_f32, 8 chains", "waves 0-3 MFMA + waves 4-7 v_pk_fma_f32", "all waves: half MFMA loop, then half v_pk_fma_f32 loop",
+                                          "waves 4-7: v_fma_f32, 16 chains (same flops)", "waves 4-7: v_pk_fma_f32, 16 chains", "all waves: v_fma_f32, half the trips each", "all waves: v_pk_fma_f32 (16 chains), half the trips each"};
+            if (rep) printf("mode %d: %.3f ms  %s  (%d x 8 MFMA 16x16x4 f32, %d x 8 v_pk_fma_f32 or their flops per wave-pair; 256 workgroups x 8 waves)\n", mode, ms, what[mode], n_mfma, n_valu);
         }
     return 0;
 }
