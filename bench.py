@@ -521,7 +521,8 @@ def main():
                                f"{'one batch at a time on one stream' if len(streams) == 1 else str(len(streams)) + ' batches in flight on ' + str(len(streams)) + ' streams'}",
                    "frames_per_utterance": T, "weights": "seeded synthetic (checkpoints are LFS pointers)",
                    "gather": "rccl all_gather of decoded waveforms" if gathered is not None else "none",
-                   "streams": len(streams)},
+                   "streams": len(streams),
+                   "library_options": {k: model.engine().get_option(k) for k in ("recurrence", "encode_fold", "decode_fold")}},
         "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms},
         "gather_ms": round(gather_ms, 3),          # rank 0's mean all-gather time per step (0: no process group, nothing to gather)
     }
