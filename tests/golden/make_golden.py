@@ -65,9 +65,56 @@ def margin(prob, nbits):
     return float((prob - 0.5).abs()[act].min())
 
 
+def edge_inputs(ref):
+    """(6, 22050) waveforms that drive the front-end's edge behaviour (meldataset.py:38-39,86-90: sqrt(.+1e-9), clamp(1e-5), log):
+    digital silence, a silent stretch inside an utterance, full-scale square wave, clipped sine, DC offset, and one second
+    of real speech from the reference's listening-test material, prepared as example.py:12-17 does."""
+    import scipy.io.wavfile
+    import scipy.signal
+    L = 22050
+    n = np.arange(L, dtype=np.float64)
+    x = np.zeros((6, L), dtype=np.float32)
+    # 0: all-zero utterance
+    noise = synth.synthetic_speech(1, L, seed=31, kind="noise")[0].numpy()
+    x[1] = noise
+    x[1, 6000:6000 + 11025] = 0.0                                                    # 1: 0.5 s of zeros inside noise
+    x[2] = np.where(np.sin(2 * np.pi * 220.0 * n / 22050.0) >= 0, 1.0, -1.0)        # 2: +-1.0 square wave
+    x[3] = np.clip(3.0 * np.sin(2 * np.pi * 440.0 * n / 22050.0), -1.0, 1.0)        # 3: clipped sine
+    x[4] = 0.5 + 0.01 * synth.synthetic_speech(1, L, seed=32, kind="noise")[0].numpy()   # 4: DC offset
+    fs, d = scipy.io.wavfile.read(os.path.join(ref, "mushra_results_dataset", "audio", "stim_01", "ref.wav"))
+    speech = d[:, 0].astype(np.float64) / 32768.0                                    # first channel (example.py:13)
+    speech = scipy.signal.resample_poly(speech, 22050, fs)                           # example.py:16 (= 147 / 160)
+    speech = speech / np.max(np.abs(speech))                                         # example.py:17
+    x[5] = speech[8000:8000 + L].astype(np.float32)                                  # 5: one second of real speech
+    return torch.from_numpy(x)
+
+
+def edges(ref, conf, ref_cfg_var, tmp, mel_spectrogram, BVRNNCodecModel, SCALING):
+    print("G1/G6 edges")
+    x = edge_inputs(ref)
+    mel = mel_spectrogram(x * SCALING, n_fft=1024, num_mels=80, sampling_rate=22050, hop_size=256,
+                          win_size=1024, fmin=0, fmax=8000, padding_left=256)
+    floor = float(np.log(1e-5))
+    print("   frames at the floor per input:", [(int((mel[i] == floor).sum()), int(mel[i].numel())) for i in range(x.shape[0])])
+    save("g1_mel_edges", x=x, mel=mel, scaling=np.float64(SCALING))
+    p1, p2 = synth.write_checkpoints(conf, tmp, seed=1234, prefix="edges")
+    model = BVRNNCodecModel(ref_cfg_var, p1, p2)
+    model.eval()
+    probs = []
+    with torch.no_grad():
+        hook = model.bvrnn.enc[5].register_forward_hook(lambda m, i, o: probs.append(o.detach().clone()))
+        codes = model.encode(x, 3000)
+        hook.remove()
+        prob = torch.stack(probs).permute(1, 0, 2)
+        wav = model.decode(codes, x.shape[1])
+    print(f"   min |p-0.5| over active bits = {margin(prob, torch.full(prob.shape[:2], 35.0)):.3e} (no seed search: the tests apply the tie rule)")
+    save("g6_e2e_edges", x=x, codes_3000=codes, prob_3000=prob, wav_3000=wav, seed=np.int64(1234))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--sets", default="all", help="all | base (G1-G6 as before) | edges (g1_mel_edges, g6_e2e_edges only)")
     a = ap.parse_args()
     sys.dont_write_bytecode = True
     install_standins()
@@ -86,6 +133,10 @@ def main():
     conf = bconfig.load_config(ref_cfg_var)
     conf64 = bconfig.load_config(ref_cfg_64)
     tmp = tempfile.mkdtemp(prefix="bvc_golden_")
+    if a.sets in ("all", "edges"):
+        edges(a.ref, conf, ref_cfg_var, tmp, mel_spectrogram, BVRNNCodecModel, SCALING)
+    if a.sets == "edges":
+        return
 
     # ---------------- G1: mel front-end -------------------------------------------------
     print("G1 mel_spectrogram")

@@ -119,6 +119,31 @@ def test_frontend_vs_reference_golden(env, name):
         assert np.abs(mel[2] - ref[2]).max() < 1e-4
 
 
+def test_frontend_edges_vs_reference_golden(env):
+    """The front-end's floor and clamp (meldataset.py:38-39,86-90) on the reference's own outputs for digital silence, a silent stretch
+    inside noise, a full-scale square wave, a clipped sine, a DC offset and one second of real speech.  Log-domain bound 2e-5
+    wherever the reference's value IS the floor log(1e-5) or lies above 10x the floor; in between (linear 1e-5 .. 1e-4, where the
+    float32 FFT's own rounding noise is comparable to the value) the linear bound of _mel_close."""
+    model = env[0]
+    g = load_golden("g1_mel_edges")
+    mel = model.mel_spectrogram(t(g["x"]).to(DEV)).cpu().numpy()
+    ref = np.transpose(g["mel"], (0, 2, 1))
+    assert mel.shape == ref.shape == (6, 86, 80)
+    floor = np.float32(np.log(np.float32(1e-5)))
+    at_floor = ref == floor
+    loud = np.exp(ref.astype(np.float64)) >= 1e-4
+    assert at_floor[0].all() and at_floor[1].sum() > 3000
+    err = np.abs(mel.astype(np.float64) - ref)
+    for i, nm in enumerate(["silence", "gap in noise", "square wave", "clipped sine", "dc offset", "real speech"]):
+        sel = at_floor[i] | loud[i]
+        print(f"{nm}: at floor {int(at_floor[i].sum())}, loud {int(loud[i].sum())} of {ref[i].size}; max |dlog| there {err[i][sel].max():.2e}, "
+              f"elsewhere {err[i][~sel].max() if (~sel).any() else 0.0:.2e}", flush=True)
+    assert (mel[at_floor] == floor).all()                   # clamped exactly where the reference clamps
+    assert err[at_floor | loud].max() <= 2e-5
+    assert _mel_close(mel, ref)
+    assert np.isfinite(mel).all()
+
+
 def test_frontend_vs_float64_truth(env):
     from oracle import frontend as ofe
     from bvcodec import synth
@@ -319,6 +344,31 @@ def test_facade_vs_reference_golden(tag):
     un = model.decode(t(g["codes_3000"]).to(DEV), 10 ** 9)
     assert un.shape == g["wav_untrimmed_3000"].shape
     assert np.sqrt(((un.cpu().numpy() - g["wav_untrimmed_3000"]) ** 2).mean()) < 1e-4
+
+
+def test_facade_edges_vs_reference_golden(env):
+    """encode / decode at 3000 bit/s on the edge inputs against the reference's outputs (tests/golden/make_golden.py --sets edges).
+    No tie-margin seed search went into this fixture, so the tie rule applies: a bit may differ only where the reference's own
+    probability is within 1e-5 of 0.5, judged at the first differing frame of an utterance; waveform RMS <= 1e-4."""
+    from parity_stats import divergence_stats
+    model = env[0]
+    g = load_golden("g6_e2e_edges")
+    x = t(g["x"]).to(DEV)
+    codes = model.encode(x, 3000).cpu().numpy()
+    st = divergence_stats(codes, g["codes_3000"], g["prob_3000"], active_bits=35)
+    print({k: st[k] for k in ("diverged_utterances", "first_divergent_frames", "max_first_divergence_margin", "bits_within_1e-5_of_a_tie")}, flush=True)
+    assert st["max_first_divergence_margin"] < 1e-5, st
+    mel = model.mel_spectrogram(x)
+    bits = torch.full(mel.shape[:2], 35.0, device=DEV)
+    _, _, prob = model.bvrnn.encode(mel, bits, torch.zeros(1, x.shape[0], 1024, device=DEV), return_prob=True)
+    ok = [b for b in range(x.shape[0]) if not (codes[b] != g["codes_3000"][b]).any()]
+    assert len(ok) >= 5                                       # (all six in practice)
+    assert np.abs(prob.cpu().numpy()[ok] - g["prob_3000"][ok]).max() < 2e-6
+    wav = model.decode(t(g["codes_3000"]).to(DEV), x.shape[1]).cpu().numpy()
+    assert wav.shape == g["wav_3000"].shape and np.isfinite(wav).all()
+    rms = np.sqrt(((wav - g["wav_3000"]) ** 2).mean(axis=1))
+    print("waveform rms error per input", rms, flush=True)
+    assert rms.max() < 1e-4                                   # north_star waveform bar, every input on its own
 
 
 def test_facade_accepts_cpu_tensors_and_returns_on_caller_device(env):

@@ -86,6 +86,38 @@ def test_frontend_matches_reference(name):
     assert (np.abs(lin64 - lin32) <= 1e-6 + 3e-6 * lin64).all()
 
 
+def test_frontend_edges_match_reference():
+    """The reference's own floor / clamp behaviour (meldataset.py:38-39,86-90: sqrt(. + 1e-9), clamp(1e-5), log) on digital silence,
+    a silent stretch inside noise, a full-scale square wave, a clipped sine, a DC offset and one second of real speech
+    (tests/golden/make_golden.py --sets edges)."""
+    g = load_golden("g1_mel_edges")
+    mel = ofe.log_mel(t(g["x"]) * ofe.SCALING).numpy()
+    assert mel.shape == g["mel"].shape == (6, 80, 86)
+    floor = np.float32(np.log(np.float32(1e-5)))
+    assert (g["mel"][0] == floor).all()                                # silence sits on the clamp in every band and frame
+    assert (g["mel"][1] == floor).sum() > 3000                         # ... and so do the frames inside the silent stretch
+    assert np.array_equal(mel == floor, g["mel"] == floor)             # the oracle clamps exactly where the reference does
+    assert np.abs(mel - g["mel"]).max() <= 2e-6
+    assert np.abs(g["x"][2]).min() == 1.0 and np.abs(g["x"][3]).max() == 1.0 and g["x"][4].mean() > 0.49
+
+
+def test_codec_edges_match_reference(conf_var):
+    """encode / decode at 3000 bit/s on the edge inputs: no tie-margin seed search here, so a bit may differ only where the reference's
+    own probability is within 1e-5 of 0.5 (and only the first differing frame of an utterance is judged: afterwards the states differ)."""
+    from parity_stats import divergence_stats
+    g = load_golden("g6_e2e_edges")
+    seed = int(g["seed"])
+    oc = ocodec.OracleCodec(conf_var, synth.bvrnn_state_dict(conf_var, seed), synth.generator_state_dict(conf_var, seed + 1))
+    r = oc.encode(t(g["x"]), 3000, full=True)
+    st = divergence_stats(r["codes"].numpy(), g["codes_3000"], g["prob_3000"], active_bits=35)
+    assert st["max_first_divergence_margin"] < 1e-5, st
+    assert st["diverged_utterances"] == 0, st                          # (in fact: the oracle reproduces every bit)
+    assert np.abs(r["prob"].numpy() - g["prob_3000"]).max() < 1e-6
+    wav = oc.decode(t(g["codes_3000"]), g["x"].shape[1]).numpy()
+    assert np.sqrt(((wav - g["wav_3000"]) ** 2).mean()) < 1e-5
+    assert np.isfinite(g["wav_3000"]).all()
+
+
 # ----------------------------------------------------------------- A5/A6/A7: BVRNN
 @pytest.mark.parametrize("tag,h_dim,var_bit", [("h1024_var", 1024, True), ("h1024_fix", 1024, False),
                                               ("h64_var", 64, True)])
