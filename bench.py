@@ -22,11 +22,13 @@ one stream.  Rank 0 prints ONE JSON line: metric/value (audio-seconds coded per 
                   default recurrence schedule ("auto") switches to the launch-per-layer kernels by itself there
   gather_ms     - mean duration of the per-step RCCL all-gather (HIP event pair on its stream; 0 without a process group)
   target_workload / encode_only / streaming - BASELINE configs[3]'s per-GPU shard (64 x 10 s, the north-star target's
-                  utterance length), configs[2] (encode only) and configs[4] (256 streams x 20 ms hops, one hipGraph-
-                  replayed library call per hop: p50 / p99), each timed after the headline with its own parity spot check
+                  utterance length; bitrates 1.5 / 3 / 6 kbit/s; with --gpus N > 1 EVERY rank runs its shard, the per-step
+                  all-gather included, max over ranks), configs[2] (encode only) and configs[4] (256 streams x 20 ms hops,
+                  one hipGraph-replayed library call per hop: p50 / p99), each timed after the headline with its own parity
+                  spot check (the last two at N = 1 only)
   cpu_baseline  - the CPU oracle (oracle/, PyTorch-CPU port of the reference op sequence) timed on the host
-                  cores on a bounded sample of the same workload (rank 0, N=1 only): 3 warm-ups, median of 5, at 8
-                  threads and at all cores.
+                  cores on a bounded sample of the same workload (rank 0, N=1 only): the benchmark's batch of 64, one
+                  second per utterance, 3 warm-ups, median of 5, at 8 threads and at all usable cores.
 
 Other workloads of BASELINE.json: ``--seconds 10`` (the north-star target's utterance length, and with
 ``--bitrate 1500|3000|6000`` one GPU's shard of configs[3]), ``--mode encode`` (configs[2]: front-end + coder only).
@@ -61,11 +63,11 @@ PROBE_NAMES = {1: "bvrnn_flow_kernel<8,encode> / <8,decode> (persistent BVRNN re
                4: "gemm_batched_(lds_)kernel (phi_x / phi_z and the frame-independent halves of enc.0, dec.0 and the GRU input gates, all frames)",
                5: "stft_logmel_kernel", 6: "conv_post_kernel"}
 def _latest(name):
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         p = os.path.join(ROOT, "profiles", f"{tag}_{name}")
         if os.path.exists(p):
             return p
-    return os.path.join(ROOT, "profiles", f"r03_{name}")
+    return os.path.join(ROOT, "profiles", f"r04_{name}")
 
 
 ROCPROF_SUMMARY = _latest("kernel_stats_default.csv")
@@ -203,7 +205,7 @@ def usable_cores():
 def cpu_baseline(oc, L, bitrate, mode):
     """the oracle on a bounded sample of the workload, 3 warm-ups, median of 5, at 8 threads (the
     reference was timed at 8 in the build container) and at all the cores this process may use."""
-    b, secs = 16, 2.0
+    b, secs = BATCH, 1.0            # the benchmark's batch (the CPU vocoder's cost depends on it), one second each
     xb = synth.synthetic_speech(b, int(FS * secs), seed=0, kind="noise")
     fn = (lambda t: oc.forward(t, bitrate)) if mode == "codec" else (lambda t: oc.encode(t, bitrate))
     allc = usable_cores()
@@ -276,22 +278,67 @@ def time_steps(fn, n, device):
     return time.perf_counter() - t0, last
 
 
-def leg_target_workload(conf, model, device, B, bitrate, with_parity, steps=5):
-    """The workload the north-star target is quoted on (10 s utterances; = one GPU's 64 of BASELINE configs[3]'s 512)."""
+def leg_target_workload(conf, model, device, B, bitrate, with_parity, steps=5, world=1, use_pg=False, rank=0, sweep=(1500.0, 6000.0)):
+    """The workload the north-star target and its scaling are quoted on: BASELINE configs[3], 512 x 10 s sharded over 8 GPUs = 64 x 10 s
+    per GPU, bitrates {1.5, 3, 6} kbit/s.  With a process group EVERY rank runs its shard and the per-step RCCL all-gather of the
+    decoded waveforms is inside the timed region (barrier + synchronize on both sides, max over ranks), so that a `--gpus N` run
+    lands on this workload too; rank 0 reports."""
     L = int(FS * 10.0)
-    x = synth.synthetic_speech(B, L, seed=1000, kind="noise").to(device)
+    x = synth.synthetic_speech(B, L, seed=1000 + rank, kind="noise").to(device)
+    gathered = torch.empty(world * B, L, device=device) if use_pg else None
+    gather_ev = []
 
-    def step():
-        codes = model.encode(x, bitrate)
-        return codes, model.decode(codes, L)
-    step()
-    dt, (codes, wav) = time_steps(step, steps, device)
-    model.check_status()
-    out = {"workload": f"BASELINE configs[3] shard: batch {B} x 10 s per GPU @ {bitrate:g} bit/s, full encode -> BigVGAN decode, one batch at a time",
-           "value": round(B * 10.0 * steps / dt, 2), "unit": "audio-seconds/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
-           "frames_per_utterance": int(codes.shape[1]), "x_real_time": round(B * 10.0 * steps / dt, 1)}
-    if with_parity:
+    def make_step(br):
+        def step():
+            codes = model.encode(x, br)
+            wav = model.decode(codes, L)
+            if gathered is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                torch.distributed.all_gather_into_tensor(gathered, wav)
+                e1.record()
+                gather_ev.append((e0, e1))
+                bdist.fence_collective(device)
+            return codes, wav
+        return step
+
+    def timed_leg(br, n):
+        step = make_step(br)
+        step()
+        gather_ev.clear()
+        if use_pg:
+            torch.distributed.barrier()
+        dt, last = time_steps(step, n, device)
+        if use_pg:
+            torch.distributed.barrier()
+        g_ms = (sum(e0.elapsed_time(e1) for e0, e1 in gather_ev) / len(gather_ev)) if gather_ev else 0.0
+        rank_ms = [round(1e3 * dt / n, 3)]
+        if use_pg:
+            tl = torch.tensor([dt], device=device, dtype=torch.float64)
+            tall = [torch.zeros_like(tl) for _ in range(world)]
+            torch.distributed.all_gather(tall, tl)
+            rank_ms = [round(1e3 * float(t.item()) / n, 3) for t in tall]
+            dt = max(float(t.item()) for t in tall)
+        model.check_status()
+        return dt, last, g_ms, rank_ms
+
+    dt, (codes, wav), g_ms, rank_ms = timed_leg(bitrate, steps)
+    out = {"workload": f"BASELINE configs[3]: batch {B} x 10 s per GPU ({world * B} x 10 s over {world} GPU{'s' if world > 1 else ''}) @ {bitrate:g} bit/s, "
+                       f"full encode -> BigVGAN decode, one batch at a time{', RCCL all-gather of the decoded waveforms per step' if use_pg else ''}",
+           "value": round(world * B * 10.0 * steps / dt, 2), "unit": "audio-seconds/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+           "n_gpus": world, "frames_per_utterance": int(codes.shape[1]), "x_real_time": round(world * B * 10.0 * steps / dt, 1),
+           "gather_ms": round(g_ms, 3), "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms}}
+    by = {f"{bitrate:g}": {"value": out["value"], "ms_per_step": out["ms_per_step"]}}
+    for br in sweep:                              # the other two bitrates of configs[3] (17 and 64 active bits per frame)
+        if br == bitrate:
+            continue
+        n2 = max(2, steps // 2)
+        dt2, _, g2, _ = timed_leg(br, n2)
+        by[f"{br:g}"] = {"value": round(world * B * 10.0 * n2 / dt2, 2), "ms_per_step": round(1e3 * dt2 / n2, 3), "gather_ms": round(g2, 3)}
+    out["by_bitrate"] = by
+    if with_parity and rank == 0:
         out["parity"] = dict(spot_check(conf, model, x[:1], codes[:1], wav[:1], L, bitrate), utterances_checked=[0])
+    del gathered
     return out
 
 
@@ -393,6 +440,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the target_workload / encode_only / streaming / large_batch legs")
+    ap.add_argument("--legs", default="target,encode,streaming,large", help="which of the extra legs run (comma separated)")
     a = ap.parse_args()
 
     # RCCL prints a version banner on STDOUT when its communicator is created; this program's stdout is one JSON line, so
@@ -595,16 +643,24 @@ def main():
     default_workload = full and a.seconds == SECONDS and B == BATCH
     if rank == 0:
         note("headline, multi_stream and roofline legs done")
-    if rank == 0 and world == 1 and default_workload and not a.no_extra:
+    legs = set() if a.no_extra else set(a.legs.split(","))
+    if default_workload and "target" in legs and (use_pg or rank == 0):
+        # with a process group every rank runs its shard of configs[3] (the gather is a collective); rank 0 reports
+        tw = leg_target_workload(conf, model, device, B, a.bitrate, not a.no_parity, world=world, use_pg=use_pg and not a.no_gather, rank=rank)
+        if rank == 0:
+            out["target_workload"] = tw
+            note("target_workload done")
+    if rank == 0 and world == 1 and default_workload:
         with_par = not a.no_parity
-        out["target_workload"] = leg_target_workload(conf, model, device, B, a.bitrate, with_par)
-        note("target_workload done")
-        out["encode_only"] = leg_encode_only(conf, model, device, x, a.bitrate, codes)
-        note("encode_only done")
-        out["streaming"] = leg_streaming(conf, model, device, a.bitrate, with_par)
-        note("streaming done")
-        out["large_batch"] = leg_large_batch(conf, model, device, a.bitrate, with_par)
-        note("large_batch done")
+        if "encode" in legs:
+            out["encode_only"] = leg_encode_only(conf, model, device, x, a.bitrate, codes)
+            note("encode_only done")
+        if "streaming" in legs:
+            out["streaming"] = leg_streaming(conf, model, device, a.bitrate, with_par)
+            note("streaming done")
+        if "large" in legs:
+            out["large_batch"] = leg_large_batch(conf, model, device, a.bitrate, with_par)
+            note("large_batch done")
     if rank == 0 and not (a.no_parity and (a.no_cpu_baseline or world > 1)):
         leg = oracle_leg(conf, model, x, codes, wav, L, a.bitrate, a.mode, with_baseline=(world == 1 and not a.no_cpu_baseline))
         if not a.no_parity:

@@ -44,6 +44,7 @@ SIGNATURES = {
     "bvc_model_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(_i32)]),
     "bvc_flow_fence": (ctypes.c_int, [_vp]),
     "bvc_model_status": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
+    "bvc_model_poll_status": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint32)]),
     "bvc_num_frames": (_i64, [_vp, _i64]),
     "bvc_vocoder_length": (_i64, [_vp, _i64]),
     "bvc_workspace_bytes": (_sz, [_vp, _i32, _i64]),
@@ -99,7 +100,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.bvc_abi_version() != 2:
+        if lib.bvc_abi_version() != 3:
             raise BvcError("libbvcodec_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -98,7 +98,11 @@ struct bvc_model {
     // recurrence schedule: RS_PERSISTENT one launch per call (k_flow.hip), RS_LAYERS one launch per layer (hipGraph replay),
     // RS_AUTO (default) persistent while calls come one at a time, layers while calls of several streams overlap
     int recurrence = 2;         // BVC_RECURRENCE=persistent|layers|auto, bvc_model_set_option("recurrence")
-    bool flow_resident = false; // the residency census at creation found a full persistent grid co-resident on this device
+    mutable bool flow_resident = false; // the residency census found a full persistent grid co-resident on this device
+    mutable bool census_due = false;    // a recurrence time-out was seen: the census runs again before the next persistent launch (another
+                                        // tenant may have arrived after bvc_model_create: the model then moves to the layer schedule)
+    mutable hipStream_t census_stream = nullptr;
+    mutable unsigned *census_ctr = nullptr;
     int flow_perh = 0;          // k-blocks per wave of an h_dim-sized segment (0: h_dim not supported by the persistent kernel)
     // sticky status word of the persistent kernels, in host-mapped pinned memory: a kernel whose wait timed out stores its
     // code there; every compute entry point reads it WITHOUT synchronising (h_status) and reports BVC_ETIMEOUT once
@@ -120,6 +124,8 @@ struct bvc_model {
 
     ~bvc_model() {
         for (auto &g : graphs) { (void)hipGraphExecDestroy(g.exec1); (void)hipGraphExecDestroy(g.execN); if (g.idle) (void)hipEventDestroy(g.idle); }
+        if (census_stream) (void)hipStreamDestroy(census_stream);
+        if (census_ctr) (void)hipFree(census_ctr);
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         if (side_stream) (void)hipStreamDestroy(side_stream);
         for (auto e : cap_events) (void)hipEventDestroy(e);
@@ -924,7 +930,7 @@ int read_state(const Workspace &w, int B, int H, int64_t T, float *d_hT, hipStre
 
 // ---- persistent recurrence (k_flow.hip): hop tables and launch -----------------------------------------
 // Is the model laid out for the persistent kernel?  (h_dim a multiple of 128 up to 1024 or below 128; narrow z / mel layers)
-int flow_census(bvc_model *m);
+int flow_census(const bvc_model *m);
 
 int build_flow(bvc_model *m) {
     const int H = m->cfg.h_dim, Z = m->cfg.z_dim, X = m->cfg.num_mels;
@@ -951,6 +957,7 @@ int sticky_status(const bvc_model *m) {
     const unsigned v = *m->h_status;
     if (!v) return BVC_OK;
     *m->h_status = 0u;
+    m->census_due = true;
     set_error("a persistent recurrence kernel of an earlier call gave up waiting (frame %u, layer %u): the results of that call "
               "are invalid.  All its workgroups must be resident together - is another process using this GPU?",
               (v & 0x7FFFFFFFu) >> 4, (v & 15u));
@@ -1030,6 +1037,15 @@ constexpr int AUTO_HOLD = 2;
 // Which schedule does THIS call take?  0: launch per layer; else utterance groups per workgroup of the persistent kernel.
 // Called once per recurrence-bearing call (run_encode / run_decode); mark_call_end() follows at its end.
 int flow_chains(const bvc_model *m, int B, hipStream_t s) {
+    if (m->census_due && !g_stream_tick) {               // a time-out was reported: is a full grid still co-resident?  (synchronises: error path only)
+        hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs0) == hipSuccess && cs0 == hipStreamCaptureStatusNone) {
+            m->census_due = false;
+            (void)flow_census(m);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     const int chains = flow_chains_static(m, B);
     if (!chains) return 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1077,25 +1093,37 @@ inline float *flow_buf(const Workspace &w, int id, int parity) { return w.flow +
 // workgroup adds itself to a counter and waits (bounded) until all have.  A CU mask, a partition mode or another tenant of the
 // device that keeps workgroups from becoming co-resident shows up here; the model then stays on the launch-per-layer schedule
 // (flow_resident = false).
-int flow_census(bvc_model *m) {
+int flow_census(const bvc_model *m) {
     m->flow_resident = false;
     const int ntg = flow_grid_tiles(m);
     int slots = m->cu_count / ntg;
     if (slots <= 0) return BVC_OK;
-    unsigned *ctr = nullptr;
-    BVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctr), 64));
-    m->allocs.push_back(ctr);
-    BVC_HIP_TRY(hipMemset(ctr, 0, 64));
+    std::lock_guard<std::mutex> lk(g_flow_mu);           // (no persistent launch of this process starts beside the census)
+    if (!m->census_ctr) BVC_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->census_ctr), 64));
+    unsigned *ctr = m->census_ctr;
+    // a stream of the library's own, synchronised on its own: neither the null stream nor hipDeviceSynchronize() is legal while
+    // another thread captures a graph
+    if (!m->census_stream) BVC_HIP_TRY(hipStreamCreateWithFlags(&m->census_stream, hipStreamNonBlocking));
     if (getenv("BVC_FLOW_CENSUS_OVERSUBSCRIBE")) slots += 1;             // tests: a grid the device cannot hold
     const int grid = ntg * slots;
-    // ~50 ms: a workgroup that has to queue behind a resident one shows up as a time-out
-    const int rc = launch_flow_census(ctr, grid, 200000u, nullptr);
-    hipError_t e = hipDeviceSynchronize();
     unsigned h[2] = {0u, 0u};
-    if (e == hipSuccess) e = hipMemcpy(h, ctr, sizeof(h), hipMemcpyDeviceToHost);
-    if (rc) return rc;
-    BVC_HIP_TRY(e);
-    m->flow_resident = h[0] == (unsigned)grid && h[1] == 0u;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        BVC_HIP_TRY(hipMemsetAsync(ctr, 0, 64, m->census_stream));
+        // ~50 ms: a workgroup that has to queue behind a resident one shows up as a time-out
+        const int rc = launch_flow_census(ctr, grid, 200000u, m->census_stream);
+        hipError_t e = hipStreamSynchronize(m->census_stream);
+        if (e == hipSuccess) e = hipMemcpy(h, ctr, sizeof(h), hipMemcpyDeviceToHost);
+        if (rc) return rc;
+        BVC_HIP_TRY(e);
+        m->flow_resident = h[0] == (unsigned)grid && h[1] == 0u;
+        if (m->flow_resident || attempt == 1) break;
+        // "device busy" is not "grid does not fit": work of this process on other streams (another model serving, say) holds
+        // compute units for a while - let it drain and count once more before giving the persistent schedule up for good
+        if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); break; }       // (illegal under a capture: keep the first answer)
+    }
+    if (!m->flow_resident && !getenv("BVC_QUIET"))
+        fprintf(stderr, "bvcodec: residency census: %u of %d recurrence workgroups became co-resident (%u gave up) - this model stays on the "
+                        "launch-per-layer schedule (get_option \"flow_resident\" = 0).  Is another process using this GPU?\n", h[0] - h[1], grid, h[1]);
     return BVC_OK;
 }
 
@@ -2046,6 +2074,9 @@ int bvc_flow_fence(void *stream) {
     std::lock_guard<std::mutex> lk(g_flow_mu);
     FlowFence &f = g_fence[dev][g_fence_n[dev]++ % FLOW_FENCES];
     if (!f.ev) BVC_HIP_TRY(hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
+    // a slot that is still pending holds a fence nobody has waited for yet (more than FLOW_FENCES fences without a persistent launch in
+    // between): order this stream behind it first, so that the new record implies the old one
+    if (f.pending) BVC_HIP_TRY(hipStreamWaitEvent(s, f.ev, 0));
     BVC_HIP_TRY(hipEventRecord(f.ev, s));
     f.pending = true;
     return BVC_OK;
@@ -2069,11 +2100,28 @@ int bvc_model_status(const bvc_model *m, uint32_t *code) {
     if (m->h_status) {
         BVC_HIP_TRY(hipDeviceSynchronize());
         v = *m->h_status;
-        if (v) *m->h_status = 0u;
+        if (v) { *m->h_status = 0u; m->census_due = true; }
     }
     if (code) *code = v;
     if (v) {
         set_error("a persistent recurrence kernel gave up waiting (frame %u, layer %u): its results are invalid",
+                  (v & 0x7FFFFFFFu) >> 4, (v & 15u));
+        return BVC_ETIMEOUT;
+    }
+    return BVC_OK;
+}
+
+int bvc_model_poll_status(const bvc_model *m, uint32_t *code) {
+    if (!m) { set_error("null model"); return BVC_EINVAL; }
+    unsigned v = 0;
+    if (m->h_status) {
+        v = *m->h_status;
+        if (v) { *m->h_status = 0u; m->census_due = true; }
+    }
+    if (code) *code = v;
+    if (v) {
+        set_error("a persistent recurrence kernel gave up waiting (frame %u, layer %u): the results of the call that has just been "
+                  "synchronised are invalid.  All its workgroups must be resident together - is another process using this GPU?",
                   (v & 0x7FFFFFFFu) >> 4, (v & 15u));
         return BVC_ETIMEOUT;
     }

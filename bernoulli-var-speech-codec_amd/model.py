@@ -117,6 +117,18 @@ class _Engine:
         with torch.cuda.device(self.device):
             _abi.check(self.lib.bvc_model_status(self.handle, ctypes.byref(code)))
 
+    def poll_status(self):
+        """The same check without synchronising (bvc_model_poll_status): for right after a blocking copy of an output."""
+        _abi.check(self.lib.bvc_model_poll_status(self.handle, None))
+
+    def deliver(self, out, out_dev):
+        """An output tensor on the caller's device.  A copy to the CPU blocks until the call has finished: the recurrence's status word is
+        then final for THIS call, and a time-out is raised here rather than by the next call."""
+        res = out.to(out_dev)
+        if torch.device(out_dev).type == "cpu":
+            self.poll_status()
+        return res
+
     def num_frames(self, L):
         return int(self.lib.bvc_num_frames(self.handle, L))
 
@@ -257,8 +269,8 @@ class BVRNN(_OnDevice):
                                                 _abi.ptr(codes), _abi.ptr(all_h), None, _abi.ptr(prob), ws, nws,
                                                 eng.stream()))
         if return_prob:
-            return codes.to(out_dev), all_h.to(out_dev), prob.to(out_dev)
-        return codes.to(out_dev), all_h.to(out_dev)
+            return codes.to(out_dev), all_h.to(out_dev), eng.deliver(prob, out_dev)
+        return codes.to(out_dev), eng.deliver(all_h, out_dev)
 
     @torch.no_grad()
     def encode_stateful(self, y, varBitrate, h):
@@ -277,7 +289,7 @@ class BVRNN(_OnDevice):
         with torch.cuda.device(eng.device):
             _abi.check(eng.lib.bvc_bvrnn_encode(eng.handle, _abi.ptr(y), _abi.ptr(bits), _abi.ptr(h0), B, T,
                                                 _abi.ptr(codes), None, _abi.ptr(hT), None, ws, nws, eng.stream()))
-        return codes.to(out_dev), hT.unsqueeze(0).to(out_dev)
+        return codes.to(out_dev), eng.deliver(hT.unsqueeze(0), out_dev)
 
     @torch.no_grad()
     def decode(self, z, h):
@@ -293,7 +305,7 @@ class BVRNN(_OnDevice):
         with torch.cuda.device(eng.device):
             _abi.check(eng.lib.bvc_bvrnn_decode(eng.handle, _abi.ptr(z), _abi.ptr(h0), B, T, _abi.ptr(mel),
                                                 _abi.ptr(hT), ws, nws, eng.stream()))
-        return mel.to(out_dev), hT.unsqueeze(0).to(out_dev)
+        return mel.to(out_dev), eng.deliver(hT.unsqueeze(0), out_dev)
 
 
 class BigVGAN(_OnDevice):
@@ -381,7 +393,7 @@ class BVRNNCodecModel(_OnDevice):
         with torch.cuda.device(eng.device):
             _abi.check(eng.lib.bvc_encode(eng.handle, _abi.ptr(x), B, L, float(SCALING), self.bits_per_frame(bitrate),
                                           _abi.ptr(codes), ws, nws, eng.stream()))
-        return codes.to(out_dev)
+        return eng.deliver(codes, out_dev)
 
     @torch.no_grad()
     def decode(self, codes, length):
@@ -400,7 +412,7 @@ class BVRNNCodecModel(_OnDevice):
             with torch.cuda.device(eng.device):
                 _abi.check(eng.lib.bvc_decode(eng.handle, _abi.ptr(codes), B, T, n, float(SCALING),
                                               _abi.ptr(wav), ws, nws, eng.stream()))
-        return wav.to(out_dev)
+        return eng.deliver(wav, out_dev)
 
     def forward(self, x, bitrate):
         """decode(encode(x, bitrate)) trimmed to the input length (bvrnn_codec_model.py:73-76)."""

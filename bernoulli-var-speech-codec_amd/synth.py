@@ -28,7 +28,9 @@ def _n(rng, shape, std=1.0, mean=0.0):
     return torch.from_numpy((mean + std * rng.standard_normal(size=shape)).astype(np.float32))
 
 
-def bvrnn_state_dict(conf, seed=1234):
+def bvrnn_state_dict(conf, seed=1234, mel_stats=None):
+    """mel_stats = (mean, std_lo, std_hi): replaces the default conditioning (mean ~ N(-4, 1), std in [0.6, 2.2]) - e.g. (-8.0, 0.05, 0.3),
+    the narrow bands a trained checkpoint may carry; every other tensor is the one the same seed gives without it."""
     rng = np.random.default_rng(seed)
     x, h, z = conf["num_mels"], conf["h_dim"], conf["z_dim"]
     sd = collections.OrderedDict()
@@ -51,6 +53,11 @@ def bvrnn_state_dict(conf, seed=1234):
     sd["rnn.weight_hh_l0"] = _u(rng, (3 * h, h), b)
     sd["rnn.bias_ih_l0"] = _u(rng, (3 * h,), b)
     sd["rnn.bias_hh_l0"] = _u(rng, (3 * h,), b)
+    if mel_stats is not None:
+        r2 = np.random.default_rng(seed + 7919)
+        mean, lo, hi = mel_stats
+        sd["mean_mel"] = _n(r2, (x,), 0.5, mean)
+        sd["std_mel"] = torch.from_numpy(r2.uniform(lo, hi, size=(x,)).astype(np.float32))
     return sd
 
 
@@ -97,12 +104,12 @@ def generator_state_dict(conf, seed=4321):
     return sd
 
 
-def write_checkpoints(conf, directory, seed=1234, prefix="synthetic"):
+def write_checkpoints(conf, directory, seed=1234, prefix="synthetic", mel_stats=None):
     """Write both checkpoints in the reference format; returns (bvrnn_path, vocoder_path)."""
     os.makedirs(directory, exist_ok=True)
-    p1 = os.path.join(directory, f"{prefix}_bvrnn_h{conf['h_dim']}_seed{seed}")
+    p1 = os.path.join(directory, f"{prefix}_bvrnn_h{conf['h_dim']}_seed{seed}{'_melstats' if mel_stats else ''}")
     p2 = os.path.join(directory, f"{prefix}_bigvgan_seed{seed}")
-    torch.save({"vrnn": bvrnn_state_dict(conf, seed)}, p1)
+    torch.save({"vrnn": bvrnn_state_dict(conf, seed, mel_stats)}, p1)
     torch.save({"generator": generator_state_dict(conf, seed + 1)}, p2)
     return p1, p2
 

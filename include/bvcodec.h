@@ -14,15 +14,18 @@
  *  - the compute entry points (bvc_stft_logmel, bvc_bvrnn_*, bvc_bigvgan, bvc_encode, bvc_decode,
  *    bvc_vocoder_stream_push, bvc_pack/unpack_codes, bvc_resample_poly, bvc_peak_normalize) are
  *    asynchronous on `stream` and use only the caller-provided workspace.  They do not allocate or
- *    synchronise, with these exceptions: the first calls per process create two HIP events, and the
- *    launch-per-layer schedule captures and instantiates a hipGraph on a stream of the library's own on
- *    the first call per (batch, workspace);
+ *    synchronise, with these exceptions: the first calls per process create a handful of HIP events (the
+ *    persistent launches' ticket, the end-of-call mark of the "auto" schedule, one per bvc_flow_fence slot in
+ *    use), the launch-per-layer schedule captures and instantiates a hipGraph on a stream of the library's own
+ *    on the first call per (batch, workspace), and the call that follows a reported time-out re-runs the
+ *    residency census (it synchronises a stream of the library's own, and the device if the census fails);
  *  - capturing into a graph of your own: allowed for every compute entry point.  While `stream` is
  *    being captured a call records no event and waits on none, and its recurrence takes the
  *    launch-per-layer kernels, launched directly into your capture (the persistent recurrence kernel is
  *    never captured: see "recurrence" below); the status word is still read when the call is ISSUED, not
  *    on replay;
- *  - bvc_model_status, bvc_probe_end, bvc_kprobe_* and the bvc_test_* helpers synchronise the device;
+ *  - bvc_model_status, bvc_probe_end, bvc_kprobe_* and the bvc_test_* helpers synchronise the device
+ *    (bvc_model_poll_status does not);
  *  - return value: 0 = BVC_OK, negative = error code; bvc_last_error() gives the text
  *    (thread-local); no C++ exception crosses the boundary;
  *  - one in-flight call per (model, workspace): calls on different streams with different
@@ -41,7 +44,8 @@
 extern "C" {
 #endif
 
-#define BVC_ABI_VERSION 2   /* 2: + bvc_model_get_option, bvc_flow_fence, bvc_kprobe_read_span; recurrence option takes 2 (auto); status word reported by every compute entry */
+#define BVC_ABI_VERSION 3   /* 2: + bvc_model_get_option, bvc_flow_fence, bvc_kprobe_read_span; recurrence option takes 2 (auto); status word reported by every compute entry
+                             * 3: + bvc_model_poll_status */
 
 enum {
     BVC_OK = 0,
@@ -139,6 +143,12 @@ int bvc_model_get_option(const bvc_model *m, const char *name, int32_t *value);
  * earlier call of this model timed out.  bvc_model_status synchronises the device first, so it also sees calls still in
  * flight; it returns BVC_ETIMEOUT and the code, and clears it; BVC_OK and 0 otherwise. */
 int bvc_model_status(const bvc_model *m, uint32_t *code);
+/* The same check WITHOUT synchronising: for a caller that has just synchronised by its own means - a blocking device-to-host copy
+ * of a call's output, hipStreamSynchronize - and wants to know whether THAT call was valid instead of learning it from the next
+ * one.  (bvcodec/model.py calls it behind every copy of an output to a CPU tensor.)  After any report of a time-out the residency
+ * census of bvc_model_create runs again before the model's next persistent launch: a tenant that arrived on the device later
+ * moves the model to the launch-per-layer schedule instead of letting every call time out. */
+int bvc_model_poll_status(const bvc_model *m, uint32_t *code);
 
 /* A persistent recurrence launch needs every compute unit of the device.  Work of the caller's own that holds compute units
  * for an unbounded time - above all an RCCL collective, whose kernel waits for its peers - must not be running beside it.

@@ -10,10 +10,10 @@ from bvcodec import BVRNNCodecModel, config, synth
 _CACHE = {}
 
 
-def make_model(var_bit=True, h_dim=1024, seed=1234, env=None):
+def make_model(var_bit=True, h_dim=1024, seed=1234, env=None, mel_stats=None):
     """Product model on cuda:0 with seeded synthetic checkpoints (+ the matching oracle state dicts).
     env: extra environment variables that are read when the engine is created (BVC_NO_GRAPH, ...)."""
-    key = (var_bit, h_dim, seed, tuple(sorted((env or {}).items())))
+    key = (var_bit, h_dim, seed, tuple(sorted((env or {}).items())), mel_stats)
     if key in _CACHE:
         return _CACHE[key]
     base = config.DEFAULT_CONFIG if var_bit else config.DEFAULT_CONFIG_64BIT
@@ -27,7 +27,7 @@ def make_model(var_bit=True, h_dim=1024, seed=1234, env=None):
             txt = f.read().replace("h_dim = 1024", f"h_dim = {h_dim}")
         with open(cfg_path, "w") as f:
             f.write(txt)
-    p1, p2 = synth.write_checkpoints(conf, d, seed=seed)
+    p1, p2 = synth.write_checkpoints(conf, d, seed=seed, mel_stats=mel_stats)
     model = BVRNNCodecModel(cfg_path, p1, p2).to("cuda:0")
     if env:                      # the library reads its switches in bvc_model_create: create the engine now
         old = {k: os.environ.get(k) for k in env}
@@ -40,7 +40,7 @@ def make_model(var_bit=True, h_dim=1024, seed=1234, env=None):
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
-    vr = synth.bvrnn_state_dict(conf, seed)
+    vr = synth.bvrnn_state_dict(conf, seed, mel_stats)
     ge = synth.generator_state_dict(conf, seed + 1)
     _CACHE[key] = (model, conf, vr, ge)
     return _CACHE[key]

@@ -20,7 +20,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/bvcodec.h but not exported"
     assert declared == set(_abi.SIGNATURES), declared ^ set(_abi.SIGNATURES)
-    assert lib.bvc_abi_version() == 2
+    assert lib.bvc_abi_version() == 3
 
 
 def test_header_is_plain_c_and_links_from_a_c_program(tmp_path):
@@ -49,7 +49,7 @@ int main(void) {
     subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), lib, f"-Wl,-rpath,{os.path.dirname(lib)}",
                            "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lstdc++"])
     out = subprocess.check_output([str(exe)], text=True).split()
-    assert out[0] == "2" and out[1] == "0"
+    assert out[0] == "3" and out[1] == "0"
 
 
 def test_config_struct_layout_matches_header():

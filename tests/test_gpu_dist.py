@@ -63,3 +63,21 @@ def test_rccl_one_rank_gather_on_picked_streams():
                MASTER_PORT=str(29600 + os.getpid() % 300), BVC_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0 and "DIST-OK" in r.stdout, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+
+
+def test_bench_target_workload_leg_runs_under_a_process_group():
+    """bench.py with a process group (what the driver's `--gpus N` runs get): the configs[3] leg - 64 x 10 s per rank, bitrates
+    1.5 / 3 / 6 kbit/s, the per-step RCCL all-gather inside the timed region - runs on every rank and is reported by rank 0."""
+    import json
+    env = dict(os.environ, BVC_FORCE_PG="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29900 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--multi-streams", "0",
+                        "--no-cpu-baseline", "--no-roofline", "--legs", "target"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["gather"].startswith("rccl") and line["gather_ms"] > 0
+    tw = line["target_workload"]
+    assert tw["n_gpus"] == 1 and tw["gather_ms"] > 0 and tw["frames_per_utterance"] == 861
+    assert set(tw["by_bitrate"]) == {"1500", "3000", "6000"} and all(v["value"] > 1000 for v in tw["by_bitrate"].values())
+    assert tw["parity"]["max_first_divergence_margin"] < 1e-5 and tw["parity"]["waveform_rms_error"] < 1e-4
+    assert len(tw["rank_ms_per_step"]["per_rank"]) == 1

@@ -171,6 +171,61 @@ def test_folded_encode_hop_vs_layer_by_layer_program_and_oracle(h_dim, B):
         assert (p1 - p0).abs().max().item() < 2e-6 and (h1 - h0_all).abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("seed,mel_stats", [(1234, None), (7, None), (99, None), (5, (-8.0, 0.05, 0.3))])
+def test_folded_encode_hop_over_several_checkpoints(seed, mel_stats):
+    """`encode_fold` on more than one weight draw: three seeded checkpoints and one with the conditioning a trained model may carry
+    (std_mel in [0.05, 0.3], mean_mel around -8: the normalisation then amplifies dec.6's rounding by up to 20).  Free-running encode of
+    16 x 40 frames with and without the fold against the float32 oracle and against the oracle in float64 ("truth"): a bit may differ
+    from the float32 oracle only where that oracle's own probability is within 1e-5 of the tie (first divergence per utterance), and
+    the folded program may not be further from the truth than the unfolded one and the float32 reference arithmetic are."""
+    from gpu_common import make_model
+    from oracle import bvrnn as obv
+    model, conf, vr, _ = make_model(True, 1024, seed=seed, mel_stats=mel_stats)
+    eng = model.engine()
+    rng = np.random.default_rng(31 * seed)
+    B, T = 16, 40
+    mean, std = vr["mean_mel"].numpy(), vr["std_mel"].numpy()
+    y = torch.from_numpy((mean + std * rng.standard_normal((B, T, 80))).astype(np.float32))      # inputs the conditioning was made for
+    bits = torch.full((B, T), 35.0)
+    h0 = torch.zeros(B, 1024)
+    r32 = obv.encode(vr, y, bits, h0)
+    r64 = obv.encode(vr, y, bits, h0, dtype=torch.float64)
+    got = {}
+    try:
+        model.set_recurrence("persistent")
+        for fold in (1, 0):
+            eng.set_option("encode_fold", fold)
+            c, _, p = model.bvrnn.encode(y.to(DEV), bits.to(DEV), h0.unsqueeze(0).to(DEV), return_prob=True)
+            got[fold] = (c.cpu(), p.cpu().double())
+        torch.cuda.synchronize()
+        model.check_status()
+    finally:
+        eng.set_option("encode_fold", 1)
+        model.set_recurrence("auto")
+
+    def common_prefix(codes):          # frames (per utterance) up to the first bit that differs from the float64 truth's codes
+        d = (codes[:, :, :35] != r64["codes"][:, :, :35].float()).any(2)
+        return torch.where(d.any(1), d.float().argmax(1), torch.full((B,), T))
+
+    def err_vs_truth(codes, prob):
+        n = common_prefix(codes)
+        e = 0.0
+        for b in range(B):
+            k = int(n[b]) + 1 if int(n[b]) < T else T      # the first differing frame still saw the same state
+            e = max(e, float((prob[b, :k, :35] - r64["prob"][b, :k, :35]).abs().max()))
+        return e, int((n < T).sum())
+
+    e_ref, d_ref = err_vs_truth(r32["codes"], r32["prob"].double())
+    e1, d1 = err_vs_truth(*got[1])
+    e0, d0 = err_vs_truth(*got[0])
+    print(f"seed {seed} mel_stats {mel_stats}: max |p - p64| float32 oracle {e_ref:.2e} ({d_ref} utterances leave the truth's codes), "
+          f"HIP folded {e1:.2e} ({d1}), HIP unfolded {e0:.2e} ({d0}); bits differing from the float32 oracle: folded "
+          f"{int((got[1][0] != r32['codes']).sum())}, unfolded {int((got[0][0] != r32['codes']).sum())}", flush=True)
+    for fold in (1, 0):
+        _ties_only(got[fold][0], r32["codes"], r32["prob"])
+    assert e1 <= 2.0 * max(e0, e_ref) + 1e-7, (e1, e0, e_ref)
+
+
 # --------------------------------------------------------------------------- edge shapes
 def test_single_frame_and_zero_length():
     """T = 1 through every stage (the facade cannot produce it: reflect padding needs L > 512, i.e. two frames) and
@@ -263,6 +318,36 @@ def test_recurrence_timeout_is_reported_by_the_next_call():
         model.set_recurrence("auto")
     assert torch.equal(model.encode(x, 3000), good)            # the status word was cleared by the report
     torch.cuda.synchronize()
+    model.check_status()
+    # (the report made the library count the co-resident workgroups again before that launch: still a full grid here)
+    assert eng.get_option("flow_resident") == 1
+
+
+def test_recurrence_timeout_is_reported_by_the_call_itself_when_its_output_goes_to_the_cpu():
+    """Where the facade synchronises anyway - the output copied to a CPU tensor for a caller who passed one - it looks at the status word
+    behind the copy (bvc_model_poll_status): the call that produced invalid results raises, not the next one."""
+    from gpu_common import make_model
+    from bvcodec import synth
+    model = make_model(True, 1024)[0]
+    eng = model.engine()
+    x = synth.synthetic_speech(8, 256 * 6 + 3, seed=1, kind="speech")          # CPU tensors in, CPU tensors out
+    good = model.encode(x, 3000)
+    assert good.device.type == "cpu"
+    try:
+        model.set_recurrence("persistent")
+        eng.set_option("flow_spin_limit", 2000)
+        eng.set_option("flow_debug_withhold", 1)
+        with pytest.raises(RuntimeError, match="just been"):
+            model.encode(x, 3000)
+        with pytest.raises(RuntimeError, match="just been"):
+            model.decode(good, x.shape[1])
+        with pytest.raises(RuntimeError, match="just been"):
+            model.bvrnn.decode(good, torch.zeros(1, 8, 1024))
+    finally:
+        eng.set_option("flow_debug_withhold", 0)
+        eng.set_option("flow_spin_limit", 4000000)
+        model.set_recurrence("auto")
+    assert torch.equal(model.encode(x, 3000), good)            # nothing is left over for the next call
     model.check_status()
 
 
