@@ -615,7 +615,6 @@ struct StepNode { int op; int branch; int event; GemmParams p; int epi; };
 enum { STEP_ENCODE = 0, STEP_DECODE = 1, STEP_DECODE_PRE = 2 };   // _PRE: phi_z halves of dec.0 / GRU arrive pre-computed
 enum { STEP_KIND_MASK = 0xF, STEP_FOLD = 0x10 };                  // | STEP_FOLD: the folded hop (step_fold below)
 constexpr int64_t SMALL_T_FRAMES = 4;          // up to this many frames per call the all-frame MLPs run frame by frame on the recurrent-layer kernel
-constexpr int64_t PRECOMP_MIN_FRAMES = 16;     // below this (streaming hops) the two extra batched GEMMs cost more than they save
 enum { EV_START = 0, EV_DEC0H = 1, EV_PZ = 2, EV_GATES = 3, EV_COUNT = 4 };
 
 // The operation sequence of ONE frame.  Every pointer is either workspace-static, frame-indexed through
@@ -678,7 +677,13 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
 
     DynPtr pz_final = (kind == STEP_ENCODE) ? S(pz3, H) : dp_frame(DS_PZ, H, 0, 1);
     if (kind == STEP_ENCODE) {
-        K(BR_MAIN, lin2_params(m->enc[0], dp_frame(DS_PX, H, 0, 1), H, h_cur, H, B, S(e1, H)), EPI_ELU);
+        {   // enc.0([phi_x, h]) = (enc.0[:, :H] phi_x + b) [all frames beforehand: encode_prologue] + enc.0[:, H:] h, as in the persistent kernel
+            GemmParams p = lin_params(m->enc[0], h_cur, B, S(e1, H));
+            p.seg[0] = mkseg(h_cur, m->enc[0].wp + (size_t)(H / 16) * 256, 2 * H / 16, H, 0);
+            p.bias0 = nullptr;
+            p.aux = dp_frame(DS_PARTD, H);
+            K(BR_MAIN, p, EPI_ELU);
+        }
         K(BR_MAIN, lin_params(m->enc[1], S(e1, H), B, S(e2, H)), EPI_ELU);
         {
             GemmParams p = lin_params(m->enc[2], S(e2, H), B, dp_frame(DS_CODES, Z));
@@ -707,7 +712,13 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
         p.aux = dp_frame(DS_PARTD, H);
         K(BR_MAIN, p, EPI_ELU);
     } else {
-        K(BR_MAIN, lin2_params(m->dec[0], pz_final, H, h_cur, H, B, S(d1, H)), EPI_ELU);
+        // both halves in the step: the h half first, then the phi_z half, chunk by chunk into the same accumulators (the order of the
+        // persistent kernel, whose filler quanta have dec.0[:, H:] h summed before phi_z exists)
+        GemmParams p = lin_params(m->dec[0], h_cur, B, S(d1, H));
+        p.nseg = 2;
+        p.seg[0] = mkseg(h_cur, m->dec[0].wp + (size_t)(H / 16) * 256, 2 * H / 16, H, 0);
+        p.seg[1] = mkseg(pz_final, m->dec[0].wp, 2 * H / 16, H, 0);
+        K(BR_MAIN, p, EPI_ELU);
     }
     (void)n_dec0;
     K(BR_MAIN, lin_params(m->dec[1], S(d1, H), B, S(d2, H)), EPI_ELU);
@@ -751,8 +762,9 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
         } else {
             p.nseg = 3;
             p.gate_il = 1;
-            p.seg[0] = mkseg(S(g3, H), m->w_ih_il, 2 * H / 16, H, 0);                 // cat([phi_x_gen, phi_z]) bvrnn.py:206
-            p.seg[1] = mkseg(pz_final, m->w_ih_il + (size_t)(H / 16) * 3 * 256, 2 * H / 16, H, 0);
+            // cat([phi_x_gen, phi_z]) bvrnn.py:206; the phi_z third first (its input exists first: the persistent kernel sums it ahead)
+            p.seg[0] = mkseg(pz_final, m->w_ih_il + (size_t)(H / 16) * 3 * 256, 2 * H / 16, H, 0);
+            p.seg[1] = mkseg(S(g3, H), m->w_ih_il, 2 * H / 16, H, 0);
             p.seg[2] = mkseg(h_cur, m->w_hh_il, H / 16, H, 1);
             p.bias0 = m->b_ih; p.bias1 = m->b_hh;
             K(BR_MAIN, p, EPI_GRU);
@@ -862,12 +874,12 @@ int get_step_graph(const bvc_model *m, const Workspace &w, void *ws_base, int B,
     return BVC_OK;
 }
 
-// Does the launch-per-layer schedule of this call fold the hop?  Encode: whenever the model does (one launch less per frame, ticks
-// included).  Decode: not on streaming hops - their one or two frames would trade T small launches for one batched GEMM.
+// Does the launch-per-layer schedule of this call fold the hop?  Whenever the model does (`encode_fold` / `decode_fold`), streaming hops
+// included: every schedule runs the same layer list, so that their results are the same bits.
 int step_fold(const bvc_model *m, bool encode, int64_t T) {
     if (!m->px0_dec3.wp || m->side_branch) return 0;
-    if (encode) return m->encode_fold ? STEP_FOLD : 0;
-    return (m->decode_fold && T > SMALL_T_FRAMES && !g_stream_tick) ? STEP_FOLD : 0;
+    (void)T;
+    return (encode ? m->encode_fold : m->decode_fold) ? STEP_FOLD : 0;
 }
 
 int run_recurrence(const bvc_model *m, const Workspace &w, void *ws_base, int B, int64_t T, int kind, hipStream_t s) {
@@ -1127,6 +1139,8 @@ int flow_census(const bvc_model *m) {
     return BVC_OK;
 }
 
+int decode_epilogue(const bvc_model *m, const float *keep, int B, int64_t T, float *d_mel, hipStream_t s);
+
 // All T frames of BVRNN.encode (encode = true) or BVRNN.decode in one launch.  w.part_dec0 (and w.part_gru for decode)
 // must hold the pre-computed halves; h0 may be null (zero state).
 int run_flow(const bvc_model *m, const Workspace &w, bool encode, int chains, const float *d_h0, int B, int64_t T, const float *d_bits,
@@ -1191,8 +1205,7 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, int chains, co
     }
     if (d_hT && (rc = launch_repack_rows(flow_buf(w, FB_H, (int)(T & 1)), d_hT, H, B, H, 1, s))) return rc;
     // folded decode: the decoder's output dec.6(u_t) for all frames at once (bvrnn.py:224-225)
-    if (a.pxc.w && d_mel &&
-        (rc = launch_gemm_batched(w.pxB, H, m->dec[3].w, H, m->dec[3].b, (int)((long long)B * T), X, H, 0, d_mel, X, s))) return rc;
+    if (a.pxc.w && d_mel && (rc = decode_epilogue(m, w.pxB, B, T, d_mel, s))) return rc;
     return BVC_OK;
 }
 
@@ -1222,6 +1235,78 @@ int batched_mlp3(const bvc_model *m, const Workspace &w, const Linear (&l)[3], c
     return launch_gemm_batched(w.pxB, H, l[2].w, H, l[2].b, BT, H, H, 1, w.pxA, H, s, GO_PACKED_FROM_UTT, T, mt16);
 }
 
+// Everything of BVRNN.encode that does not depend on the recurrence, for all frames: phi_x(yn) (bvrnn.py:178) and the phi_x half of
+// enc.0 with its bias (bvrnn.py:189) -> w.part_dec0, natural (B,T,H).  The batched GEMMs for a whole utterance; on a streaming hop
+// (1-2 frames: B*T rows fill a handful of their 128x128 tiles, 102 us per 1024^2 layer at 256 streams) the recurrent-layer kernel
+// frame by frame (10 us).  Same bits either way (one order of summation: k_gemm.hip).
+int encode_prologue(const bvc_model *m, const Workspace &w, int B, int64_t T, hipStream_t s) {
+    const int H = m->cfg.h_dim, X = m->cfg.num_mels;
+    const int mt16 = ((B + 15) / 16) * 16;
+    int rc;
+    if (T <= SMALL_T_FRAMES) {
+        for (int64_t t = 0; t < T; ++t) {
+            float *px = w.pxA + t * (int64_t)mt16 * H;
+            if ((rc = launch_gemm_skinny(lin_params(m->phi_x[0], dp_static(w.yn + t * X, T * X), B, dp_static(w.pxC, H, 1)), EPI_ELU, s, m->mtw))) return rc;
+            if ((rc = launch_gemm_skinny(lin_params(m->phi_x[1], dp_static(w.pxC, H, 1), B, dp_static(w.pxB, H, 1)), EPI_ELU, s, m->mtw))) return rc;
+            if ((rc = launch_gemm_skinny(lin_params(m->phi_x[2], dp_static(w.pxB, H, 1), B, dp_static(px, H, 1)), EPI_ELU, s, m->mtw))) return rc;
+            GemmParams p = lin_params(m->enc[0], dp_static(px, H, 1), B, dp_static(w.part_dec0 + t * H, T * H));
+            p.seg[0] = mkseg(dp_static(px, H, 1), m->enc[0].wp, 2 * H / 16, H, 0);
+            finish(p);
+            if ((rc = launch_gemm_skinny(p, EPI_LINEAR, s, m->mtw))) return rc;
+        }
+        return BVC_OK;
+    }
+    const int BT = (int)((long long)B * T);
+    if ((rc = launch_gemm_batched(w.yn, X, m->phi_x[0].w, X, m->phi_x[0].b, BT, H, X, 1, w.pxC, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxC, H, m->phi_x[1].w, H, m->phi_x[1].b, BT, H, H, 1, w.pxB, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxB, H, m->phi_x[2].w, H, m->phi_x[2].b, BT, H, H, 1, w.pxC, H, s))) return rc;
+    return launch_gemm_batched(w.pxC, H, m->enc[0].w, 2 * H, m->enc[0].b, BT, H, H, 0, w.part_dec0, H, s);
+}
+
+// ... and of BVRNN.decode (the codes are known): phi_z(z) (bvrnn.py:223), the phi_z half of dec.0 with its bias (bvrnn.py:224) ->
+// w.part_dec0 (B,T,H), and the phi_z half of the GRU's input gates with b_ih (bvrnn.py:227) -> w.part_gru (B,T,3H).
+int decode_prologue(const bvc_model *m, const Workspace &w, const float *d_codes, int B, int64_t T, hipStream_t s) {
+    const int H = m->cfg.h_dim, Z = m->cfg.z_dim;
+    const int mt16 = ((B + 15) / 16) * 16;
+    int rc;
+    if (T <= SMALL_T_FRAMES) {
+        for (int64_t t = 0; t < T; ++t) {
+            float *pz = w.pxA + t * (int64_t)mt16 * H;
+            if ((rc = launch_gemm_skinny(lin_params(m->phi_z[0], dp_static(d_codes + t * Z, T * Z), B, dp_static(w.pxC, H, 1)), EPI_ELU, s, m->mtw))) return rc;
+            if ((rc = launch_gemm_skinny(lin_params(m->phi_z[1], dp_static(w.pxC, H, 1), B, dp_static(w.pxB, H, 1)), EPI_ELU, s, m->mtw))) return rc;
+            if ((rc = launch_gemm_skinny(lin_params(m->phi_z[2], dp_static(w.pxB, H, 1), B, dp_static(pz, H, 1)), EPI_ELU, s, m->mtw))) return rc;
+            GemmParams p = lin_params(m->dec[0], dp_static(pz, H, 1), B, dp_static(w.part_dec0 + t * H, T * H));
+            p.seg[0] = mkseg(dp_static(pz, H, 1), m->dec[0].wp, 2 * H / 16, H, 0);
+            finish(p);
+            if ((rc = launch_gemm_skinny(p, EPI_LINEAR, s, m->mtw))) return rc;
+            GemmParams q;
+            memset(&q, 0, sizeof(q));
+            q.nseg = 1;
+            q.seg[0] = mkseg(dp_static(pz, H, 1), m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0);
+            q.M = B; q.N = 3 * H; q.bias0 = m->b_ih;
+            q.y = dp_static(w.part_gru + t * 3 * H, T * 3 * H);
+            finish(q);
+            if ((rc = launch_gemm_skinny(q, EPI_LINEAR, s, m->mtw))) return rc;
+        }
+        return BVC_OK;
+    }
+    const int BT = (int)((long long)B * T);
+    if ((rc = launch_gemm_batched(d_codes, Z, m->phi_z[0].w, Z, m->phi_z[0].b, BT, H, Z, 1, w.pxC, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxC, H, m->phi_z[1].w, H, m->phi_z[1].b, BT, H, H, 1, w.pxB, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxB, H, m->phi_z[2].w, H, m->phi_z[2].b, BT, H, H, 1, w.pxC, H, s))) return rc;
+    if ((rc = launch_gemm_batched(w.pxC, H, m->dec[0].w, 2 * H, m->dec[0].b, BT, H, H, 0, w.part_dec0, H, s))) return rc;
+    return launch_gemm_batched(w.pxC, H, m->w_ih_nat + H, 2 * H, m->b_ih, BT, 3 * H, H, 0, w.part_gru, 3 * H, s);
+}
+
+// dec.6 over the kept u = ELU(dec.4) of all frames (the folded hop): the decoder's output mel^ (bvrnn.py:224-225)
+int decode_epilogue(const bvc_model *m, const float *keep, int B, int64_t T, float *d_mel, hipStream_t s) {
+    const int H = m->cfg.h_dim, X = m->cfg.num_mels;
+    const int BT = (int)((long long)B * T);
+    if (T <= SMALL_T_FRAMES)
+        return launch_gemm_skinny(lin_params(m->dec[3], dp_static(keep, H), BT, dp_static(d_mel, X)), EPI_LINEAR, s, m->mtw);
+    return launch_gemm_batched(keep, H, m->dec[3].w, H, m->dec[3].b, BT, X, H, 0, d_mel, X, s);
+}
+
 int run_encode_body(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_mel, const float *d_bits,
                     const float *d_h0, int B, int64_t T, float *d_codes, float *d_all_h, float *d_hT, float *d_prob,
                     hipStream_t s) {
@@ -1229,24 +1314,17 @@ int run_encode_body(const bvc_model *m, const Workspace &w, void *ws_base, const
     const long long BT = (long long)B * T;
     int rc;
     if (m->cfg.var_bit && !d_bits) { set_error("bits per frame required when var_bit=1"); return BVC_EINVAL; }
+    if (m->side_branch) { set_error("BVC_SIDE_BRANCH: the side-branch experiment of round 1 is no longer wired into encode"); return BVC_EINVAL; }
     // y = (y - mean) / std ; phi_x over all frames (bvrnn.py:173-178)
     if ((rc = launch_normalize_rows(d_mel, m->mean_mel, m->std_mel, BT, X, w.yn, s))) return rc;
     const int chains = flow_chains(m, B, s);
-    if (chains) {
-        // ... and so is the phi_x half of enc.0 (bvrnn.py:189): part = enc.0[:, :H] phi_x(y_t) + b, all frames at once
-        const int iBT = (int)BT;
-        if ((rc = launch_gemm_batched(w.yn, X, m->phi_x[0].w, X, m->phi_x[0].b, iBT, H, X, 1, w.pxC, H, s))) return rc;
-        if ((rc = launch_gemm_batched(w.pxC, H, m->phi_x[1].w, H, m->phi_x[1].b, iBT, H, H, 1, w.pxB, H, s))) return rc;
-        if ((rc = launch_gemm_batched(w.pxB, H, m->phi_x[2].w, H, m->phi_x[2].b, iBT, H, H, 1, w.pxC, H, s))) return rc;
-        if ((rc = launch_gemm_batched(w.pxC, H, m->enc[0].w, 2 * H, m->enc[0].b, iBT, H, H, 0, w.part_dec0, H, s))) return rc;
-        return run_flow(m, w, true, chains, d_h0, B, T, d_bits, d_codes, d_prob, d_all_h, nullptr, d_hT, s);
-    }
-    if ((rc = batched_mlp3(m, w, m->phi_x, w.yn, X, B, T, s))) return rc;
+    if ((rc = encode_prologue(m, w, B, T, s))) return rc;
+    if (chains) return run_flow(m, w, true, chains, d_h0, B, T, d_bits, d_codes, d_prob, d_all_h, nullptr, d_hT, s);
     if ((rc = init_state(w, d_h0, B, H, s))) return rc;
     if (d_all_h && (rc = launch_repack_rows(w.hbuf, d_all_h, (long long)T * H, B, H, 1, s))) return rc;
     CallDesc d;
     memset(&d, 0, sizeof(d));
-    d.p[DS_PX] = w.pxA; d.p[DS_CODES] = d_codes; d.p[DS_BITS] = const_cast<float *>(d_bits);
+    d.p[DS_PARTD] = w.part_dec0; d.p[DS_CODES] = d_codes; d.p[DS_BITS] = const_cast<float *>(d_bits);
     d.p[DS_PROB] = d_prob; d.p[DS_ALLH] = d_all_h;
     d.T = T;
     const int kind_e = STEP_ENCODE | step_fold(m, true, T);
@@ -1273,17 +1351,11 @@ int run_decode_body(const bvc_model *m, const Workspace &w, void *ws_base, const
     memset(&d, 0, sizeof(d));
     const int chains = flow_chains(m, B, s);
     const bool flow = chains > 0;
-    const bool pre = flow || (m->precomp_pz && T >= PRECOMP_MIN_FRAMES);
+    const bool pre = flow || m->precomp_pz;            // (BVC_NO_PRECOMP=1: the round-1 step with both halves inside, another order of summation)
     const int kind = pre ? STEP_DECODE_PRE : STEP_DECODE;
     if (pre) {
-        // ... and so do the phi_z halves of dec.0 (bvrnn.py:224) and of the GRU's input product (bvrnn.py:227): two more
-        // batched GEMMs (89 TFLOP/s) take 4 of the 15.4 layer-equivalents per frame out of the recurrence (29 TFLOP/s)
-        const int BT = (int)((long long)B * T);
-        if ((rc = launch_gemm_batched(d_codes, Z, m->phi_z[0].w, Z, m->phi_z[0].b, BT, H, Z, 1, w.pxC, H, s))) return rc;
-        if ((rc = launch_gemm_batched(w.pxC, H, m->phi_z[1].w, H, m->phi_z[1].b, BT, H, H, 1, w.pxB, H, s))) return rc;
-        if ((rc = launch_gemm_batched(w.pxB, H, m->phi_z[2].w, H, m->phi_z[2].b, BT, H, H, 1, w.pxC, H, s))) return rc;
-        if ((rc = launch_gemm_batched(w.pxC, H, m->dec[0].w, 2 * H, m->dec[0].b, BT, H, H, 0, w.part_dec0, H, s))) return rc;
-        if ((rc = launch_gemm_batched(w.pxC, H, m->w_ih_nat + H, 2 * H, m->b_ih, BT, 3 * H, H, 0, w.part_gru, 3 * H, s))) return rc;
+        // ... and so do the phi_z halves of dec.0 (bvrnn.py:224) and of the GRU's input product (bvrnn.py:227)
+        if ((rc = decode_prologue(m, w, d_codes, B, T, s))) return rc;
         d.p[DS_PARTD] = w.part_dec0; d.p[DS_PARTG] = w.part_gru;
         if (flow) return run_flow(m, w, false, chains, d_h0, B, T, nullptr, nullptr, nullptr, nullptr, d_mel, d_hT, s);
     } else {
@@ -1298,8 +1370,7 @@ int run_decode_body(const bvc_model *m, const Workspace &w, void *ws_base, const
     if ((rc = begin_call(m, w, d, count_kernels(build_step(m, w, B, kind_d)), s))) return rc;
     if ((rc = run_recurrence(m, w, ws_base, B, T, kind_d, s))) return rc;
     if (d_hT && (rc = read_state(w, B, H, T, d_hT, s))) return rc;
-    if ((kind_d & STEP_FOLD) && d_mel &&                // the decoder's output dec.6(u_t), all frames at once (bvrnn.py:224-225)
-        (rc = launch_gemm_batched(w.pxB, H, m->dec[3].w, H, m->dec[3].b, (int)((long long)B * T), m->cfg.num_mels, H, 0, d_mel, m->cfg.num_mels, s))) return rc;
+    if ((kind_d & STEP_FOLD) && d_mel && (rc = decode_epilogue(m, w.pxB, B, T, d_mel, s))) return rc;     // the decoder's output, all frames at once
     return BVC_OK;
 }
 

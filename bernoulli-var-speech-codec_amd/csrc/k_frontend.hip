@@ -140,7 +140,10 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(FrontendTables t, cons
             const float *w = t.mel_w + t.mel_off[j];
             float acc = 0.0f;
             for (int i = 0; i < ln; ++i) acc = fmaf(w[i], mag[st + i], acc);
-            if (live) mel[f * t.num_mels + j] = logf(acc < 1e-5f ? 1e-5f : acc);      // torch.clamp(min=1e-5) keeps a NaN (fmaxf would not)
+            // torch.clamp(min=1e-5) keeps a NaN (fmaxf would not).  The logarithm goes through double precision and is rounded once: ocml's
+            // logf is good to about two units in the last place - it gave -11.512927 for the floor itself, where the reference's
+            // torch.log gives the correctly rounded -11.512925 (meldataset.py:38-39) - and 80 logarithms per frame cost nothing
+            if (live) mel[f * t.num_mels + j] = (float)log((double)(acc < 1e-5f ? 1e-5f : acc));
         }
         // next iteration's first LDS write (bufA) is ordered after this iteration's last read of
         // bufA by the two barriers above; mag/zbuf are rewritten only after further barriers.

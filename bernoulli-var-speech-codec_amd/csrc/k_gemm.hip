@@ -14,6 +14,14 @@
 //                        tile, 64x64 per wave (4x4 MFMA tiles), operands loaded as k-contiguous
 //                        float4 fragments.
 //
+// ONE order of summation per output, whichever kernel computes a layer (the persistent recurrence kernel of k_flow.hip, the
+// launch-per-layer kernel below, the batched kernels): the K/16 k-blocks of a segment are cut into NCHUNK = 8 chunks - chunk c =
+// blocks [nb*c/8, nb*(c+1)/8) -, a chunk is a chain of MFMAs over its blocks in k order starting from zero, the chunks are added
+// in ascending order (the first one is copied), then the bias, then an optional pre-computed addend, then the activation.  In the
+// recurrent kernels a chunk is a wave's share of the split K; the batched kernels run the chunks one after the other in the same
+// accumulators.  A layer over a concatenated input [x1 | x2] cuts EACH segment into its 8 chunks and chains chunk c of x2 behind
+// chunk c of x1 in the same accumulator.  So a code bit does not depend on the schedule that computed it.
+//
 // Reference semantics: nn.Linear / nn.ELU / nn.Sigmoid / torch.round / nn.GRU as used at
 // bvrnn.py:44-83,163-229.
 #include <cstdlib>
@@ -192,18 +200,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
 #pragma unroll
         for (int q = 0; q < NG; ++q) { acc0[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    const int nb = p.nb_total;
-    const int my_lo = (int)(((long long)nb * wave) / NW);
-    const int my_hi = (int)(((long long)nb * (wave + 1)) / NW);
-
-    int base = 0;
+    // every segment is cut over the waves on its own (wave w = chunk w of the summation order, see the head of this file): the
+    // accumulator of a wave chains its chunk of the first segment, then its chunk of the second, ...
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         if (s > 0 && s >= p.nseg) break;
         const int sb = p.seg[s].K >> 4;
-        int lo = my_lo - base, hi = my_hi - base;
-        lo = lo < 0 ? 0 : lo;
-        hi = hi > sb ? sb : hi;
+        const int lo = (int)(((long long)sb * wave) / NW);
+        const int hi = (int)(((long long)sb * (wave + 1)) / NW);
         if (lo < hi) {
             // floats between k-blocks / between gates: [n/16][k/16][lane][4] per gate, or gate-interleaved [n/16][k/16][gate][lane][4]
             constexpr long long kbs = GIL ? NG * 256 : 256;
@@ -218,7 +222,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
                     run_segment<NG, U, MTW>(wl, gate_stride, kbs, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc1);
             }
         }
-        base += sb;
     }
 
     // ---- cross-wave reduction through LDS, fixed order (deterministic)
@@ -353,12 +356,9 @@ static int allow_lds(K kern, int bytes) {
 
 int skinny_kernels_init() {
     int rc;
-    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 16, 1, 1, true>, 16 * 6 * 1024))) return rc;
-    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 16, 1, 1, false>, 16 * 6 * 1024))) return rc;
-    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 12, 1, 1, true>, 12 * 6 * 1024))) return rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 8, 1, 1, true>, 8 * 6 * 1024))) return rc;
+    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 8, 1, 1, false>, 8 * 6 * 1024))) return rc;
     if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 8, 3, 2, true>, 8 * 6 * 2 * 1024))) return rc;
-    if ((rc = allow_lds(gemm_skinny_kernel<3, 2, 4, 2, 4, true>, 4 * 6 * 4 * 1024))) return rc;
-    if ((rc = allow_lds(gemm_skinny_kernel<1, 1, 16, 4, 4>, 16 * 4 * 1024))) return rc;
     return BVC_OK;
 }
 
@@ -391,21 +391,15 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s, int mtw) {
     static const bool latency_mode = getenv("BVC_LATENCY") != nullptr && getenv("BVC_LATENCY")[0] == '1';
     ProbeScope probe((epi == EPI_GRU || epi == EPI_GRU_PART) ? PK_GRU : PK_LINEAR, s);
     if (p.gate_il && epi != EPI_GRU) { set_error("gemm_skinny: gate-interleaved weights are for the GRU launch only"); return BVC_EINVAL; }
+    // EIGHT waves everywhere: a wave is one chunk of the summation order (head of this file), so the wave count is part of the result.
+    // (Round 1 ran the GRU launch and the K = 2048 layers on 12 / 16 waves for 2 % more throughput with three chains in flight.)
     if (epi == EPI_GRU) {
-        // chunks of ONE k-block: 15.3 us against 17.0 us with chunks of two (and 0.082 against 0.061 launches/us with three
-        // chains in tools/gru_splitk_bench.hip): a 16-wave workgroup that bursts 8 KiB of loads per wave only queues them
-        if (!p.gate_il)    launch_skinny_t<3, 2, 16, 1, 1, false>(p, epi, s);
-        else if (mtw == 4) launch_skinny_t<3, 2, 4, 2, 4, true>(p, epi, s);
-        else if (mtw == 2) launch_skinny_t<3, 2, 8, 3, 2, true>(p, epi, s);
-        else if (latency_mode) launch_skinny_t<3, 2, 16, 1, 1, true>(p, epi, s);
-        else                   launch_skinny_t<3, 2, 12, 1, 1, true>(p, epi, s);     // 12 waves: +2 % over 16 with three chains in flight
+        // chunks of ONE k-block in flight: a workgroup that bursts 8 KiB of loads per wave only queues them (tools/gru_splitk_bench.hip)
+        if (!p.gate_il)    launch_skinny_t<3, 2, 8, 1, 1, false>(p, epi, s);
+        else if (mtw >= 2) launch_skinny_t<3, 2, 8, 3, 2, true>(p, epi, s);       // (mtw 4: two row tiles per workgroup here - four sets of partial tiles exceed the LDS)
+        else               launch_skinny_t<3, 2, 8, 1, 1, true>(p, epi, s);
     } else if (epi == EPI_GRU_PART) {
         launch_skinny_t<3, 1, 8, 4, 1>(p, epi, s);
-    } else if (nb >= 128) {          // K >= 2048: 16 waves
-        if (mtw == 4)      launch_skinny_t<1, 1, 16, 4, 4>(p, epi, s);
-        else if (mtw == 2) launch_skinny_t<1, 1, 16, 8, 2>(p, epi, s);
-        else if (latency_mode) launch_skinny_t<1, 1, 16, 4, 1>(p, epi, s);
-        else                   launch_skinny_t<1, 1, 12, 1, 1>(p, epi, s);
     } else {
         // mtw 1: chunks of 4 k-blocks (52 VGPRs) measured 2 % faster than chunks of 8 (88 VGPRs), alone and
         // with three chains in flight
@@ -477,11 +471,11 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
     const int n0 = blockIdx.x * 128 + (wave & 1) * 64;
     if (m0 >= M || n0 >= N) return;                                  // wave-uniform
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][4], tot[4][4];                          // the running chunk | the sum of the finished chunks (head of this file)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; tot[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     const float *xp[4];
     const float *wp[4];
@@ -498,6 +492,9 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
     // The fragments of k-block kb+1 are requested before block kb is multiplied (unconditionally: past the end the last block
     // is read again), so that only the first request's latency is exposed - these are the K = 64 / 80 first layers, five blocks.
     const int nblk = K >> 4;
+    int chunk = 0, cend = nblk >> 3;                       // chunk c = blocks [nblk*c/8, nblk*(c+1)/8)
+    while (cend == 0) { ++chunk; cend = (nblk * (chunk + 1)) >> 3; }
+    bool first_chunk = true;
     f32x4 xv[4], wv[4], xn[4], wn[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -523,7 +520,22 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xv[i] = xn[i]; wv[i] = wn[i]; }
+        if (kb + 1 == cend) {                              // (uniform) block kb ends chunk `chunk`: add it to the sum, start the next one from zero
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    tot[i][j] = first_chunk ? acc[i][j] : tot[i][j] + acc[i][j];
+                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            first_chunk = false;
+            do { ++chunk; cend = (nblk * (chunk + 1)) >> 3; } while (chunk < 7 && cend == kb + 1);     // (empty chunks: K < 128)
+        }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = tot[i][j];
     if (ROWVEC) {                                          // acc[i][j][e] = y[m0 + 16 i + r][n0 + 16 j + 4 g + e]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -569,7 +581,7 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restri
 // MFMAs, and is parked in the other LDS buffer afterwards (one barrier per stage).  Rows are padded to
 // 36 floats so that the 16-byte fragment reads of 8 consecutive lanes cover all banks.  The k order seen
 // by each accumulator is the one of gemm_batched_kernel (16-blocks in order, k = 4*g + e inside), so both
-// produce the same bits.
+// produce the same bits: eight chunks of K/8, each a chain from zero, added in order (head of this file).
 // BM: rows per workgroup tile, 128 or 64 (the half-height form finishes the last, partly filled round of a launch: see
 // launch_gemm_batched); m_off: first row of this launch's tiles.
 template <int ACT, int BM, bool ROWVEC = false>
@@ -599,11 +611,11 @@ __global__ __launch_bounds__(256, 2) void gemm_batched_lds_kernel(const float *_
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) wg[p] = w + (long long)(nblk + srow + 32 * p) * ldw + spc;
-    f32x4 acc[MI][4];
+    f32x4 acc[MI][4], tot[MI][4];                        // the running chunk | the sum of the finished chunks (head of this file)
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; tot[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     constexpr int STAGE = (BM + 128) * LDT;              // floats per LDS buffer
     f32x4 ga[PA], gb[4];
@@ -621,12 +633,13 @@ __global__ __launch_bounds__(256, 2) void gemm_batched_lds_kernel(const float *_
         for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(B + (srow + 32 * p) * LDT + spc) = gb[p];
     };
     const int nk = K / BK;
+    const int cst = nk >> 3;                             // stages per chunk (K is a multiple of 256: launch_gemm_batched)
     gload(0);
     park(0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) gload(kt + 1);
+    // one 32-deep stage; FIRST: the stage opens a chunk - its first MFMA per tile starts from zero (no accumulator to clear)
+    auto stage = [&](int kt, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
         const float *A = smem + (kt & 1) * STAGE + (wm + r) * LDT + g * 4;
         const float *B = smem + (kt & 1) * STAGE + BM * LDT + (wn + r) * LDT + g * 4;
 #pragma unroll
@@ -641,12 +654,39 @@ __global__ __launch_bounds__(256, 2) void gemm_batched_lds_kernel(const float *_
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = ROWVEC ? mfma16(bv[j][e], av[i][e], acc[i][j]) : mfma16(av[i][e], bv[j][e], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 c = (FIRST && h == 0 && e == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j];
+                        acc[i][j] = ROWVEC ? mfma16(bv[j][e], av[i][e], c) : mfma16(av[i][e], bv[j][e], c);
+                    }
+        }
+    };
+    int in_chunk = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        if (in_chunk == 0) stage(kt, std::true_type());
+        else               stage(kt, std::false_type());
+        if (++in_chunk == cst) {                         // (uniform) the chunk is complete: add it to the sum
+            in_chunk = 0;
+            if (kt < cst) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tot[i][j] = acc[i][j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tot[i][j] += acc[i][j];
+            }
         }
         if (more) park((kt + 1) & 1);
         __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = tot[i][j];
 
     const int m0 = mblk + wm, n0 = nblk + wn;
     if (ROWVEC) {           // operands swapped (tile of y^T): acc[i][j][e] = y[m0 + 16 i + r][n0 + 16 j + 4 g + e], one 16-byte granule in every
@@ -705,7 +745,7 @@ int launch_gemm_batched(const float *x, long long ldx, const float *w, long long
     dim3 grid((N + 127) / 128, (M + 127) / 128);
     ProbeScope probe(PK_BATCHED, s);
     static const bool no_lds = getenv("BVC_NO_LDS_GEMM") != nullptr;      // A/B switch for the profiles
-    if (!no_lds && K % 32 == 0 && K >= 256 && N % 128 == 0) {
+    if (!no_lds && K % 256 == 0 && N % 128 == 0) {          // (eight chunks of whole 32-deep stages)
         const size_t lds = (size_t)2 * 2 * 128 * 36 * sizeof(float);
         static bool attr = false;
         if (!attr) {

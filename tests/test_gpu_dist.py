@@ -43,11 +43,8 @@ for sched in ("persistent", "auto"):
         torch.cuda.current_stream(device).wait_stream(st)
     torch.cuda.synchronize()
     model.check_status()
-    for o in outs:
-        if sched == "persistent":
-            assert torch.equal(o, wav0), "gathered waveform differs from the local one"
-        else:                                       # (the layer schedule sums in another order: same codes up to ties, waveform to rounding)
-            assert (o - wav0).abs().max().item() < 1e-3
+    for o in outs:                                  # (whichever kernels 'auto' picked: one order of summation per output)
+        assert torch.equal(o, wav0), "gathered waveform differs from the local one"
 model.set_recurrence("auto")
 c2, w2 = bdist.codec_sharded(model, x, 3000, gather=True)
 assert torch.equal(c2, codes0) and torch.equal(w2, wav0)

@@ -72,6 +72,28 @@ def test_batched_linear(lib, M, N, K):
     assert (y.cpu().double() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("M", [5, 100, 300, 2000])
+@pytest.mark.parametrize("N,K", [(1024, 1024), (1024, 80), (1024, 64), (80, 1024), (1024, 256), (1024, 2048), (3072, 1024)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_recurrent_layer_kernel_and_batched_kernels_give_the_same_bits(lib, M, N, K, act):
+    """One order of summation per output (head of k_gemm.hip: eight chunks of the k-blocks, each a chain from zero, added in order,
+    then the bias): the launch-per-layer kernel (K split over eight waves) and the batched kernels (one accumulator chain per
+    output, folded per chunk) must agree bit for bit - this is what makes a streaming hop, which runs phi_x / phi_z frame by frame
+    on the former, emit the same codes as the offline call, which runs them on the latter."""
+    from bvcodec import _abi
+    g = torch.Generator().manual_seed(7 * M + N + K + act)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / np.sqrt(K)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    st = _abi.current_stream(torch.device(DEV))
+    y1 = torch.full((M, N), float("nan"), device=DEV)
+    y2 = torch.full((M, N), float("nan"), device=DEV)
+    _abi.check(lib.bvc_test_linear(_abi.ptr(x), _abi.ptr(w), _abi.ptr(b), M, N, K, act, _abi.ptr(y1), st))
+    _abi.check(lib.bvc_test_linear_batched(_abi.ptr(x), _abi.ptr(w), _abi.ptr(b), M, N, K, act, _abi.ptr(y2), st))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2), (y1 - y2).abs().max().item()
+
+
 @pytest.mark.parametrize("M,tail_rows", [(11129, 32), (11982, 64)])
 def test_batched_linear_tail_tiles_equal_full_tiles(lib, M, tail_rows):
     """launch_gemm_batched: the rows of the last, partly filled round of 128-row tiles go out as a second launch of quarter-
@@ -121,25 +143,32 @@ def test_frontend_vs_reference_golden(env, name):
 
 def test_frontend_edges_vs_reference_golden(env):
     """The front-end's floor and clamp (meldataset.py:38-39,86-90) on the reference's own outputs for digital silence, a silent stretch
-    inside noise, a full-scale square wave, a clipped sine, a DC offset and one second of real speech.  Log-domain bound 2e-5
-    wherever the reference's value IS the floor log(1e-5) or lies above 10x the floor; in between (linear 1e-5 .. 1e-4, where the
-    float32 FFT's own rounding noise is comparable to the value) the linear bound of _mel_close."""
+    inside noise, a full-scale square wave, a clipped sine, a DC offset and one second of real speech.
+    * where the reference's value IS the floor log(1e-5), ours is that same float;
+    * where it is the floor or lies above 10x the floor: |d log mel| <= 2e-5 against the reference - unless the reference's own
+      float32 STFT is further than that from the float64 truth of the same operator sequence (tonal input with 100 dB between peak
+      and valley: clipped sine 7e-4, DC offset 2.5e-4, speech 2.3e-5), where the bar is twice the reference's own distance;
+    * everywhere: the linear bound of _mel_close."""
+    from oracle import frontend as ofe
     model = env[0]
     g = load_golden("g1_mel_edges")
     mel = model.mel_spectrogram(t(g["x"]).to(DEV)).cpu().numpy()
     ref = np.transpose(g["mel"], (0, 2, 1))
     assert mel.shape == ref.shape == (6, 86, 80)
+    m64 = ofe.log_mel(t(g["x"]).double() * ofe.SCALING, dtype=torch.float64).permute(0, 2, 1).numpy()
     floor = np.float32(np.log(np.float32(1e-5)))
     at_floor = ref == floor
     loud = np.exp(ref.astype(np.float64)) >= 1e-4
     assert at_floor[0].all() and at_floor[1].sum() > 3000
-    err = np.abs(mel.astype(np.float64) - ref)
+    assert (mel[at_floor] == floor).all()                   # clamped exactly where the reference clamps, to the same float
     for i, nm in enumerate(["silence", "gap in noise", "square wave", "clipped sine", "dc offset", "real speech"]):
         sel = at_floor[i] | loud[i]
-        print(f"{nm}: at floor {int(at_floor[i].sum())}, loud {int(loud[i].sum())} of {ref[i].size}; max |dlog| there {err[i][sel].max():.2e}, "
-              f"elsewhere {err[i][~sel].max() if (~sel).any() else 0.0:.2e}", flush=True)
-    assert (mel[at_floor] == floor).all()                   # clamped exactly where the reference clamps
-    assert err[at_floor | loud].max() <= 2e-5
+        d_ref = np.abs(mel[i].astype(np.float64) - ref[i])[sel].max()
+        e_hip = np.abs(mel[i] - m64[i])[sel].max()
+        e_ref = np.abs(ref[i] - m64[i])[sel].max()
+        print(f"{nm}: at floor {int(at_floor[i].sum())}, loud {int(loud[i].sum())} of {ref[i].size}; there max |dlog| vs reference {d_ref:.2e}; "
+              f"vs float64 truth: ours {e_hip:.2e}, the reference's {e_ref:.2e}", flush=True)
+        assert d_ref <= 2e-5 or e_hip <= 2.0 * e_ref, (nm, d_ref, e_hip, e_ref)
     assert _mel_close(mel, ref)
     assert np.isfinite(mel).all()
 
