@@ -459,7 +459,7 @@ __device__ __forceinline__ long long out_index(int row, int col, int N, long lon
 // results are four CONSECUTIVE COLUMNS of one output row and leave as one 16-byte store (the K = 64 / 80 first layers are bound by
 // their 113 MB of output: 64 four-byte stores per lane otherwise).  Same products, same order of summation per output.
 template <int ACT, bool ROWVEC = false>
-__global__ __launch_bounds__(256) void gemm_batched_kernel(const float *__restrict__ x, long long ldx,
+__global__ __launch_bounds__(256, 2) void gemm_batched_kernel(const float *__restrict__ x, long long ldx,
                                                            const float *__restrict__ w, long long ldw,
                                                            const float *__restrict__ bias, int M, int N,
                                                            int K, float *__restrict__ y, long long ldy,
