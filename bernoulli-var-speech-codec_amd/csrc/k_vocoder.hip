@@ -29,6 +29,18 @@ namespace bvc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// xs / num_kernels (models.py:225), a true IEEE division like the reference's - in ONE of a stage's nine launches.  The test is uniform,
+// but hipcc turns `if (epi == DIV) o = o / d` into the division (a dozen vector instructions per element) on EVERY launch plus a select;
+// the empty asm statement cannot be speculated, so the division stays behind a scalar branch (a fifth of these kernels' vector
+// instructions were this).
+__device__ __forceinline__ void divide_if(bool div, f32x4 &v, float d) {
+    if (div) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] / d;
+    }
+}
+
 struct ConvArgs {
     const float *in;  long long Lin;
     float *out;       long long Lout;
@@ -199,10 +211,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             f32x4 v = acc[i][n] + *reinterpret_cast<const f32x4 *>(a.bias + col);
             if (a.epi >= CE_RES) v = v + *reinterpret_cast<const f32x4 *>(a.res + o);        // x = xt + x      (models.py:119)
             if (a.epi >= CE_RES_ACC) v = *reinterpret_cast<const f32x4 *>(a.acc + o) + v;    // xs += resblock  (models.py:224)
-            if (a.epi == CE_RES_ACC_DIV) {                                                   // xs / num_kernels (models.py:225)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] / a.divisor;
-            }
+            divide_if(a.epi == CE_RES_ACC_DIV, v, a.divisor);                                // xs / num_kernels (models.py:225)
             *reinterpret_cast<f32x4 *>(a.out + o) = v;
         }
     }
@@ -537,9 +546,9 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
         for (int e = 0; e < 4; ++e) {
             float o = v[e] + resq[i][e];                             // x = xt + x      (models.py:119)
             if (a.epi >= CE_RES_ACC) o = accq[i][e] + o;             // xs += resblock  (models.py:224)
-            if (a.epi == CE_RES_ACC_DIV) o = o / a.divisor;          // xs / num_kernels (models.py:225)
             v[e] = o;
         }
+        divide_if(a.epi == CE_RES_ACC_DIV, v, a.divisor);            // xs / num_kernels (models.py:225)
         reinterpret_cast<f32x4 *>(a.out + ob)[idx] = v;
     }
     PHASE(5);
@@ -752,9 +761,9 @@ __global__ __launch_bounds__(256, OCC) void amp_pair8_kernel(AmpArgs a) {
             for (int e = 0; e < 4; ++e) {
                 float o = o4[e] + resq[i][e];                            // x = xt + x      (models.py:119)
                 if (a.epi >= CE_RES_ACC) o = accq[i][e] + o;             // xs += resblock  (models.py:224)
-                if (a.epi == CE_RES_ACC_DIV) o = o / a.divisor;          // xs / num_kernels (models.py:225)
                 o4[e] = o;
             }
+            divide_if(a.epi == CE_RES_ACC_DIV, o4, a.divisor);           // xs / num_kernels (models.py:225)
             reinterpret_cast<f32x4 *>(a.out + ob)[idx] = o4;
         }
         if (!more) break;
@@ -973,9 +982,9 @@ __global__ __launch_bounds__(256, OCC) void amp_pair16_kernel(AmpArgs a) {
             for (int e = 0; e < 4; ++e) {
                 float o = o4[e] + resq[i][e];                            // x = xt + x      (models.py:119)
                 if (a.epi >= CE_RES_ACC) o = accq[i][e] + o;             // xs += resblock  (models.py:224)
-                if (a.epi == CE_RES_ACC_DIV) o = o / a.divisor;          // xs / num_kernels (models.py:225)
                 o4[e] = o;
             }
+            divide_if(a.epi == CE_RES_ACC_DIV, o4, a.divisor);           // xs / num_kernels (models.py:225)
             *reinterpret_cast<f32x4 *>(a.out + ob + row * C + g * 4) = o4;
         }
         if (!more) break;

@@ -65,6 +65,44 @@ __device__ __forceinline__ void valu16_loop(int iters, float seed, float *sink) 
     if (s == 12345.678f) *sink = s;
 }
 
+// integer vector instructions (address arithmetic, masks): 16 independent chains
+__device__ __forceinline__ void int_loop(int iters, float seed, float *sink) {
+    unsigned v[16];
+    for (int i = 0; i < 16; ++i) v[i] = (unsigned)(seed * 1000.f) + i + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = (v[i] << 1) + (v[i] ^ 0x9E3779B9u);       // v_lshl_add / v_xor: two per chain and trip
+    }
+    unsigned s = 0;
+    for (int i = 0; i < 16; ++i) s += v[i];
+    if (s == 12345678u) *sink = (float)s;
+}
+// one wave: MFMAs with independent vector instructions between them (does a wave's own vector work hide behind its MFMAs?)
+template <int KIND>
+__device__ __forceinline__ void mixed_loop(int iters, float seed, float *sink) {
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (f32x4){seed, seed, seed, seed};
+    const float a = seed + 1.0f, b = seed * 0.5f;
+    float v[16];
+    f32x2 w[8];
+    for (int i = 0; i < 16; ++i) v[i] = seed + i;
+    for (int i = 0; i < 8; ++i) w[i] = (f32x2){seed + i, seed - i};
+    const float m = 1.0000001f, c = 1e-7f;
+    const f32x2 m2 = {1.0000001f, 0.9999999f}, c2 = {1e-7f, -1e-7f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+            if (KIND == 0) { v[2 * i] = __builtin_fmaf(v[2 * i], m, c); v[2 * i + 1] = __builtin_fmaf(v[2 * i + 1], m, c); }     // two v_fma_f32 per MFMA
+            else w[i] = __builtin_elementwise_fma(w[i], m2, c2);                                                                // one v_pk_fma_f32 per MFMA
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3] + w[i][0] + w[i][1];
+    for (int i = 0; i < 16; ++i) s += v[i];
+    if (s == 12345.678f) *sink = s;
+}
+
 __global__ __launch_bounds__(512) void k(int mode, int n_mfma, int n_valu, float seed, float *sink) {
     const int wave = threadIdx.x >> 6;
     if (mode == 0) { if (wave < 4) mfma_loop(n_mfma, seed, sink); }
@@ -74,7 +112,14 @@ __global__ __launch_bounds__(512) void k(int mode, int n_mfma, int n_valu, float
     else if (mode == 4) { if (wave >= 4) scalar_loop(n_valu, seed, sink); }           // 16 v_fma_f32 per trip = the flops of 8 v_pk_fma_f32
     else if (mode == 5) { if (wave >= 4) valu16_loop(n_valu / 2, seed, sink); }       // 16 v_pk_fma_f32 per trip, half the trips
     else if (mode == 6) { scalar_loop(n_valu / 2, seed, sink); }                      // two waves per SIMD, ordinary FMAs
-    else { valu16_loop(n_valu / 4, seed, sink); }                                     // two waves per SIMD, packed FMAs
+    else if (mode == 7) { valu16_loop(n_valu / 4, seed, sink); }                      // two waves per SIMD, packed FMAs
+    else if (mode == 8) { if (wave < 4) mfma_loop(n_mfma, seed, sink); else scalar_loop(n_valu, seed, sink); }     // MFMA wave + ordinary-FMA wave per SIMD
+    else if (mode == 9) { if (wave >= 4) int_loop(n_valu, seed, sink); }
+    else if (mode == 10) { if (wave < 4) mfma_loop(n_mfma, seed, sink); else int_loop(n_valu, seed, sink); }       // MFMA wave + integer wave per SIMD
+    else if (mode == 11) { if (wave < 4) mixed_loop<0>(n_mfma, seed, sink); }          // one wave per SIMD: 2 v_fma_f32 behind every MFMA
+    else if (mode == 12) { if (wave < 4) mixed_loop<1>(n_mfma, seed, sink); }          // one wave per SIMD: 1 v_pk_fma_f32 behind every MFMA
+    else if (mode == 13) { mixed_loop<0>(n_mfma / 2, seed, sink); }                    // two waves per SIMD, each half the trips of mode 11
+    else { mixed_loop<1>(n_mfma / 2, seed, sink); }
 }
 
 int main(int argc, char **argv) {
@@ -85,15 +130,18 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 0; mode < 8; ++mode) {
+        for (int mode = 0; mode < 15; ++mode) {
             hipEventRecord(e0);
             hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, mode, n_mfma, n_valu, 0.001f, sink);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms = 0.f;
             hipEventElapsedTime(&ms, e0, e1);
-            static const char *what[8] = {"waves 0-3: MFMA loop", "waves 4-7: v_pk_fma_f32, 8 chains", "waves 0-3 MFMA + waves 4-7 v_pk_fma_f32", "all waves: half MFMA loop, then half v_pk_fma_f32 loop",
-                                          "waves 4-7: v_fma_f32, 16 chains (same flops)", "waves 4-7: v_pk_fma_f32, 16 chains", "all waves: v_fma_f32, half the trips each", "all waves: v_pk_fma_f32 (16 chains), half the trips each"};
+            static const char *what[15] = {"waves 0-3: MFMA loop", "waves 4-7: v_pk_fma_f32, 8 chains", "waves 0-3 MFMA + waves 4-7 v_pk_fma_f32", "all waves: half MFMA loop, then half v_pk_fma_f32 loop",
+                                          "waves 4-7: v_fma_f32, 16 chains (same flops)", "waves 4-7: v_pk_fma_f32, 16 chains", "all waves: v_fma_f32, half the trips each", "all waves: v_pk_fma_f32 (16 chains), half the trips each",
+                                          "waves 0-3 MFMA + waves 4-7 v_fma_f32 (modes 0 + 4 at once)", "waves 4-7: integer (v_lshl_add, v_xor), 16 chains", "waves 0-3 MFMA + waves 4-7 integer (modes 0 + 9 at once)",
+                                          "waves 0-3: every MFMA followed by 2 independent v_fma_f32", "waves 0-3: every MFMA followed by 1 independent v_pk_fma_f32",
+                                          "all waves: MFMA + 2 v_fma_f32, half the trips each", "all waves: MFMA + 1 v_pk_fma_f32, half the trips each"};
             if (rep) printf("mode %d: %.3f ms  %s  (%d x 8 MFMA 16x16x4 f32, %d x 8 v_pk_fma_f32 or their flops per wave-pair; 256 workgroups x 8 waves)\n", mode, ms, what[mode], n_mfma, n_valu);
         }
     return 0;
