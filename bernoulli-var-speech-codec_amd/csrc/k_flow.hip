@@ -106,7 +106,19 @@ struct FlowWg {
     unsigned *status;
 };
 
+//   BVC_FLOW_MAXCHK       1 (default): "does a fetched block still hold the sentinel" as an unsigned maximum over the block's dwords (two v_max3_u32 and a
+//                         compare per 16 bytes instead of four compares and three ors); nothing but the sentinel itself may then lie at or above
+//                         it: publishable() maps every such bit pattern (negative NaNs with an all-ones payload top) to the canonical NaN
+#ifndef BVC_FLOW_MAXCHK
+#define BVC_FLOW_MAXCHK 1
+#endif
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ bool is_poison4(const u32x4 v) {
+    if (BVC_FLOW_MAXCHK) return umax3(umax3(v[0], v[1], v[2]), v[3], 0u) >= FLOW_POISON;
     return v[0] == FLOW_POISON || v[1] == FLOW_POISON || v[2] == FLOW_POISON || v[3] == FLOW_POISON;
 }
 
@@ -138,11 +150,20 @@ __device__ __forceinline__ FlowSrc flow_wait(const FlowWg &g, unsigned buf, int 
     return s;
 }
 
+//   BVC_FLOW_INORDER      1 (default): a segment's operand blocks are requested strictly in k order and multiplied in that order, each as soon as IT has
+//                         arrived (a wave's loads return in order), with the sentinel checks behind the last product.  hipcc otherwise
+//                         schedules the checks - which need every block - in front of the first product and requests block 0 second to
+//                         last: all eight blocks then have to be there before the first MFMA issues
+#ifndef BVC_FLOW_INORDER
+#define BVC_FLOW_INORDER 1
+#endif
 template <int PER>
 __device__ __forceinline__ void flow_issue(const FlowWg &g, const FlowSrc &s, u32x4 (&xr)[PER]) {
 #pragma unroll
-    for (int u = 0; u < PER; ++u)
+    for (int u = 0; u < PER; ++u) {
         xr[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(g.rs, s.vl, s.base + (unsigned)u * 1024u, AUX_SC1));
+        if (BVC_FLOW_INORDER) __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // Lane's view of a run of weight blocks: a wave-uniform byte pointer (kept in SGPRs, re-derived every frame so that the
@@ -154,6 +175,8 @@ __device__ __forceinline__ GPtr uniform_ptr(const float *w, size_t block) {
     return (GPtr)p;
 }
 __device__ __forceinline__ f32x4 wload(GPtr ub, unsigned lane16, int blk) {
+    // (Measured and not kept: the part of blk * 1024 beyond the instruction's 4095-byte immediate moved into an opaque SCALAR base - a
+    // third fewer 64-bit vector adds in front of the reduction barrier, and 0.15 ms per step slower: profiles/r04_flow_variants.txt)
     return *reinterpret_cast<const f32x4 __attribute__((address_space(1))) *>(ub + lane16 + (unsigned)blk * 1024u);
 }
 
@@ -212,10 +235,15 @@ __device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int
         bool bad = false;
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            bad |= is_poison4(xr[u]);
+            if (!BVC_FLOW_INORDER) bad |= is_poison4(xr[u]);
             const f32x4 xv = __builtin_bit_cast(f32x4, xr[u]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) a2 = mfma16(wv[u][e], xv[e], a2);
+            if (BVC_FLOW_INORDER) __builtin_amdgcn_sched_barrier(0);       // block u's products before block u + 1 is waited for
+        }
+        if (BVC_FLOW_INORDER) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) bad |= is_poison4(xr[u]);
         }
         if (!(__any(bad) && !give_up)) {
             acc = a2;
@@ -346,7 +374,7 @@ __device__ __forceinline__ u32x4 publishable(f32x4 o, bool rowok) {
     u32x4 b = __builtin_bit_cast(u32x4, o);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (b[j] == FLOW_POISON) b[j] = 0x7FC00000u;       // never publish the sentinel as data
+        if (BVC_FLOW_MAXCHK ? b[j] >= FLOW_POISON : b[j] == FLOW_POISON) b[j] = 0x7FC00000u;       // never publish the sentinel as data
         if (!rowok) b[j] = 0u;                             // padding rows of the last utterance group stay zero
     }
     return b;
