@@ -79,6 +79,39 @@ namespace {
 #ifndef BVC_GRU_FAST
 #define BVC_GRU_FAST 0
 #endif
+//   BVC_GRU_FENCE         1 (default): scheduling fences around the rounds of the GRU layer's weight stream (see flow_gru)
+//   BVC_GRU_DEPTH         register sets the stream runs through (default 3; 2: the request for round i + 1 in front of round i's products; up to all four rounds)
+//   BVC_GRU_PRE           1: (h_dim 1024, filler form) round 0 of the GRU layer's weight stream is requested by the layer in front of it, phi_x.4,
+//                         in front of ITS reduction barrier - where every other layer requests its successor's weights -, round 1 at the GRU
+//                         layer's entry, rounds 2 and 3 behind the operand fetch.  Whatever a wave requests at the entry returns, in order,
+//                         BEFORE its flag poll: two rounds there (96 KiB per compute unit) held the polls back for 1.7 us
+//   BVC_FLOW_PARKV        2 (default; 0 off, 1 two layers): (filler form) the weights of two wide layers (three in decode) - this wave's 8 blocks each - stay in registers for the whole launch
+//                         (the filler kernels use 165 of the 256 VGPRs a wave may have): 128 KiB per compute unit and frame less to pull from
+//                         the L2, whose fill path into the compute units is what the kernel is bound by
+#ifndef BVC_FLOW_PARKV
+#define BVC_FLOW_PARKV 2
+#endif
+//   BVC_FLOW_PARKL        1 (default): (filler form) the FIRST layer's weights (enc.0 / dec.0, the half that multiplies h) stay in LDS for the whole launch - the
+//                         64 KiB that the kernel's 128 KiB left of a compute unit's 160 - instead of being requested by every frame's GRU layer,
+//                         at the most crowded point of the frame
+#ifndef BVC_FLOW_PARKL
+#define BVC_FLOW_PARKL 1
+#endif
+#ifndef BVC_FLOW_PARK_SET
+#define BVC_FLOW_PARK_SET 1                          // which two: 1 dec.2 + dec.4, 0 phi_x.2 + phi_x.4
+#endif
+#ifndef BVC_GRU_PRE
+#define BVC_GRU_PRE 0
+#endif
+#ifndef BVC_GRU_FENCE_CHAINS
+#define BVC_GRU_FENCE_CHAINS 0                       // the same fences in flow_gru_chains (batches beyond 64 utterances)
+#endif
+#ifndef BVC_GRU_FENCE
+#define BVC_GRU_FENCE 1
+#endif
+#ifndef BVC_GRU_DEPTH
+#define BVC_GRU_DEPTH 3
+#endif
 #ifndef BVC_FLOW_POLL_SLEEP
 #define BVC_FLOW_POLL_SLEEP 1                        // s_sleep units (64 clocks) between two polls of a wave
 #endif
@@ -380,6 +413,12 @@ __device__ __forceinline__ u32x4 publishable(f32x4 o, bool rowok) {
     return b;
 }
 
+template <bool C, typename A, typename B>
+__device__ __forceinline__ decltype(auto) pick(A &a, B &b) {
+    if constexpr (C) return (a);
+    else return (b);
+}
+
 // per-workgroup state of the frame loop
 // The kernel arguments are read through a constant-address-space pointer that is made opaque once per frame: their
 // fields then come in by scalar loads where they are used, instead of ~100 SGPRs being filled (and spilled) up front.
@@ -401,6 +440,7 @@ struct FlowCtx {
                              // load there is a cache round trip on the critical path)
     LdsX stash;              // BVC_FLOW_STASH: this wave's operand blocks of the quanta's input
     LdsX gpark;              // BVC_GRU_FAST: this wave's parked quarter of the GRU layer's weights: [6 blocks][lane]
+    LdsX lpark;              // BVC_FLOW_PARKL: this wave's eight blocks of the first layer's weights (same LDS as gpark: one or the other)
     volatile unsigned __attribute__((address_space(3))) *pubflag;      // BVC_FLOW_PARTNER_WAIT: hop count of wave 0's last publishing store
     unsigned par;            // frame parity
     long long t, fr;         // frame; (utterance, frame) index of this lane's row
@@ -500,7 +540,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
             fill_issue<PERN, FGATE>(g, fill, fw, fx);
             fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc, c.stash);
         }
-        if (BVC_GRU_FAST && GRUPRE) {
+        if ((BVC_GRU_FAST || BVC_GRU_PRE) && GRUPRE) {
 #pragma unroll
             for (int i = 0; i < GRU_EARLY_BLOCKS; ++i) gq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};     // defined on every path (see wn)
         }
@@ -565,6 +605,11 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
         const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
+    }
+    if (BVC_GRU_PRE && !BVC_GRU_FAST && GRUPRE) {          // round 0 of the GRU layer's weights (two k-blocks x three gates)
+        const GPtr ug = uniform_ptr(a.w_ihx, ((size_t)g.ntile * 2 * a.hb + wave * PER) * 3 * g.wmul);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gq[i] = wload(ug, (unsigned)lane * 16u, i);
     }
     // The quantum's operands are requested in front of the barrier and multiplied behind it.  (Round 2 measured the other orders with
     // the quantum's input re-fetched from memory: the publishing wave requesting its own behind its store, or every wave behind the
@@ -867,6 +912,32 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         gru_round6<PER>(gq + 6, xa, 4, gi);
         gru_round6<PER>(gq, xa, 6, gi);
         __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (FILL && PER == 8 && BVC_GRU_PRE) {
+        // four rounds of two k-blocks x three gates, in k order (the sums of the generic form below).  Round 0 has been on its way since
+        // phi_x.4's reduction barrier (gq[0..5]); round 1 is requested now, rounds 2 and 3 only behind the operand fetch.
+        const unsigned l16 = (unsigned)lane * 16u;
+        const GPtr ux = uniform_ptr(a.w_ihx, ((size_t)g.ntile * 2 * hb + wave * PER) * 3 * g.wmul);
+        u32x4 xa[PER];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gq[6 + i] = wload(ux, l16, 6 + i);                    // round 1
+        __builtin_amdgcn_sched_barrier(0);
+        gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * c.sb, hb, xa, c.give_up, code);
+        if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 2);
+        f32x4 g2[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g2[i] = wload(ux, l16, 12 + i);                       // round 2
+        __builtin_amdgcn_sched_barrier(0);
+        gru_round6<PER>(gq, xa, 0, gi);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gq[i] = wload(ux, l16, 18 + i);                       // round 3 into round 0's registers
+        __builtin_amdgcn_sched_barrier(0);
+        gru_round6<PER>(gq + 6, xa, 2, gi);
+        __builtin_amdgcn_sched_barrier(0);
+        gru_round6<PER>(g2, xa, 4, gi);
+        __builtin_amdgcn_sched_barrier(0);
+        gru_round6<PER>(gq, xa, 6, gi);
+        __builtin_amdgcn_sched_barrier(0);
     } else if (!(PER == 1 && wave >= hb)) {                // (wave-uniform) a wave without a k-block of its own contributes zeros
         constexpr int HALF = FILL ? (PER >= BVC_GRU_ROUNDS_FILL ? PER / BVC_GRU_ROUNDS_FILL : 1) : (PER >= 4 ? PER / 4 : 1);       // k-blocks per round
         constexpr int RPS = PER / HALF;                    // rounds per segment
@@ -878,26 +949,35 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         const GPtr uz = uniform_ptr(a.w_ihz, ((size_t)g.ntile * 2 * hb + kb0) * 3 * g.wmul);
         const GPtr ux = uniform_ptr(a.w_ihx, ((size_t)g.ntile * 2 * hb + kb0) * 3 * g.wmul);
         u32x4 xa[PER], xb[PER];
-        f32x4 wr[2][HALF][3];
-        gru_issue_w<HALF>(FILL ? ux : uh, l16, 0, wr[0]);
+        // The weights stream through DEPTH register sets: the request for round i + DEPTH - 1 is issued before round i is multiplied.
+        // The scheduling fences make that true: hipcc sinks a load to just in front of its first use when left alone (it schedules
+        // for few live registers although this kernel may use all 256), and every round then waited a full cache round trip for
+        // its own weights - the GRU hop measured 6 us against the 2.6 us its 192 MFMAs per SIMD take.
+        constexpr int DEPTH = (FILL && BVC_GRU_DEPTH > 2) ? (BVC_GRU_DEPTH < NR ? BVC_GRU_DEPTH : NR) : 2;
+        f32x4 wr[DEPTH][HALF][3];
+        auto wsrc = [&](int i) { const int sn = i / RPS; return FILL ? ux : (sn == 0 ? uh : ((ENCODE && sn == 1) ? uz : ux)); };
+#pragma unroll
+        for (int i = 0; i < DEPTH - 1; ++i)
+            if (i < NR) gru_issue_w<HALF>(wsrc(i), l16, (i % RPS) * HALF, wr[i]);
         if (!FILL) gru_issue_known<PER>(g, hbuf + c.par * c.sb, hb, xa);
         if (!FILL && ENCODE) gru_issue_known<PER>(g, (unsigned)(FB_Q3 * 2 + c.par) * c.sb, hb, xb);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int sg = i / RPS, h0 = (i % RPS) * HALF;
-            if (i + 1 < NR) {
-                const int sn = (i + 1) / RPS, hn0 = ((i + 1) % RPS) * HALF;
-                gru_issue_w<HALF>(FILL ? ux : (sn == 0 ? uh : ((ENCODE && sn == 1) ? uz : ux)), l16, hn0, wr[(i + 1) & 1]);
-            }
-            if (i == (NSEG - 1) * RPS)                     // the last segment's input, phi_x(d_t): wait, fetch, verify
+            if (i + DEPTH - 1 < NR) gru_issue_w<HALF>(wsrc(i + DEPTH - 1), l16, ((i + DEPTH - 1) % RPS) * HALF, wr[(i + DEPTH - 1) % DEPTH]);
+            if (BVC_GRU_FENCE) __builtin_amdgcn_sched_barrier(0);
+            if (i == (NSEG - 1) * RPS) {                   // the last segment's input, phi_x(d_t): wait, fetch, verify
                 gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * c.sb, hb, xa, c.give_up, code);
-            if (FILL)                   gru_round<PER, HALF>(wr[i & 1], xa, h0, gi);
-            else if (sg == 0)           gru_round<PER, HALF>(wr[i & 1], xa, h0, gh);
-            else if (ENCODE && sg == 1) gru_round<PER, HALF>(wr[i & 1], xb, h0, gi);
-            else                        gru_round<PER, HALF>(wr[i & 1], xa, h0, gi);
+                if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 2);        // (here: flags seen AND operands fetched)
+            }
+            if (FILL)                   gru_round<PER, HALF>(wr[i % DEPTH], xa, h0, gi);
+            else if (sg == 0)           gru_round<PER, HALF>(wr[i % DEPTH], xa, h0, gh);
+            else if (ENCODE && sg == 1) gru_round<PER, HALF>(wr[i % DEPTH], xb, h0, gi);
+            else                        gru_round<PER, HALF>(wr[i % DEPTH], xa, h0, gi);
+            if (BVC_GRU_FENCE) __builtin_amdgcn_sched_barrier(0);
         }
     }
-    gru_epilogue<ENCODE, PERN, NW>(c, hopid, hb, n0, ytile, gi, gh, nxt, wn, c.pre_now);
+    gru_epilogue<ENCODE, PERN, NW>(c, hopid, hb, n0, ytile, gi, gh, nxt, wn, c.pre_now && !(BVC_FLOW_PARKL && FILL && PER == 8));
 }
 
 // MULTI: the GRU cell for the chains of this workgroup, two chains at a time: a round's weights (two k-blocks x three gates, streamed
@@ -948,6 +1028,7 @@ __device__ __forceinline__ void flow_gru_chains(FlowCtx &c, int hopid, int hb, c
                 const int sn = (i + 1) / RPS, hn0 = ((i + 1) % RPS) * HALF;
                 gru_issue_w<HALF>(sn == 0 ? uh : ((ENCODE && sn == 1) ? uz : ux), l16, hn0, wr[(i + 1) & 1]);
             }
+            if (BVC_GRU_FENCE_CHAINS) __builtin_amdgcn_sched_barrier(0);       // (the request for round i + 1 really in front of round i's products: see flow_gru)
             // a chain's operand blocks of the NEXT segment are requested as soon as its last round of this one is multiplied: they
             // travel under the partner's round (phi_x(d_t), produced last, is waited for, fetched and verified; h and phi_z are known)
             const bool seg_end = (i % RPS == RPS - 1) && i + 1 < NR;
@@ -966,6 +1047,7 @@ __device__ __forceinline__ void flow_gru_chains(FlowCtx &c, int hopid, int hb, c
                 if (next_fresh) { if (two) gru_fetch_fresh<PER>(gB, (unsigned)(FB_G3 * 2 + c.par) * c.sb, hb, xB, c.give_up, code); }
                 else            gru_issue_known<PER>(gB, (unsigned)(FB_Q3 * 2 + c.par) * c.sb, hb, xB);
             }
+            if (BVC_GRU_FENCE_CHAINS) __builtin_amdgcn_sched_barrier(0);
         }
         // the two cells' epilogues, one after the other (one set of partial tiles in LDS)
         for (int k = 0; k < (two ? 2 : 1); ++k) {
@@ -1023,7 +1105,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     c.red_chain = lds + 2 * NW * 256 + NW * 6 * 256;      // (MULTI only: FLOW_LDS_MULTI)
     c.stash = (LdsX)(lds + 2 * NW * 256) + (tid >> 6) * (PERH * 64);
     c.gpark = (LdsX)(lds + 2 * NW * 256 + NW * 8 * 256) + (tid >> 6) * (6 * 64);
-    c.pubflag = (volatile unsigned __attribute__((address_space(3))) *)(lds + 2 * NW * 256 + NW * 8 * 256 + NW * 6 * 256);
+    c.lpark = (LdsX)(lds + 2 * NW * 256 + NW * 8 * 256) + (tid >> 6) * (8 * 64);
+    static_assert(!(BVC_FLOW_PARKL && BVC_GRU_FAST), "one use of the parking region");
+    c.pubflag = (volatile unsigned __attribute__((address_space(3))) *)(lds + 2 * NW * 256 + NW * 8 * 256 + NW * 8 * 256);
     if (FILL && tid == 0) c.pubflag[0] = 0xFFFFFFFFu;
     c.g.lane = tid & 63;
     c.g.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1054,18 +1138,46 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     f32x4 wa[PERH], wb[PERH], w1[1];
     f32x4 gq[GRU_EARLY_BLOCKS];                            // BVC_GRU_FAST: the GRU layer's early-requested weights (rounds 0, 1)
     constexpr bool GFAST = FILL && PERH == 8 && BVC_GRU_FAST && !MULTI;
+    constexpr bool GPRE = FILL && PERH == 8 && (BVC_GRU_FAST || BVC_GRU_PRE) && !MULTI;    // phi_x.4 requests GRU weights early
     if (GFAST && hfull) {                                  // park round 2 (k-blocks 4, 5 x three gates) of this wave's share of W_ih[:, :H]
         const GPtr ux = uniform_ptr(ap->w_ihx, (((size_t)c.g.ntile * 2 * hb + c.g.wave * PERH) * 3 + 12) * c.g.wmul);
 #pragma unroll
         for (int i = 0; i < 6; ++i) c.gpark[i * 64 + c.g.lane] = __builtin_bit_cast(u32x4, wload(ux, (unsigned)c.g.lane * 16u, i));
+    }
+    // BVC_FLOW_PARKV: wide layers whose weights - this wave's eight blocks each - stay in registers for the whole launch.  Layers that
+    // carry a filler quantum first (their waves request two weight sets in front of the reduction barrier otherwise): dec.2, dec.4; decode has
+    // registers for a third: phi_x.4
+    constexpr bool PK = BVC_FLOW_PARKV && FILL && !MULTI;
+    constexpr bool PL = BVC_FLOW_PARKL && FILL && !MULTI && PERH == 8;
+    constexpr bool P8 = PK && BVC_FLOW_PARK_SET == 1, P9 = PK && (BVC_FLOW_PARK_SET == 1 || (!ENCODE && BVC_FLOW_PARKV >= 2)),
+                   P12 = PK && BVC_FLOW_PARK_SET == 0, P13 = PK && (BVC_FLOW_PARK_SET == 0 || (!ENCODE && BVC_FLOW_PARKV >= 2));
+    f32x4 k8[P8 ? PERH : 1], k9[P9 ? PERH : 1], k12[P12 ? PERH : 1], k13[P13 ? PERH : 1];
+    {
+        auto park = [&](auto &k, const FlowLin l) {
+            const GPtr u = uniform_ptr(l.w, hfull ? (size_t)c.g.ntile * l.wnb + c.g.wave * PERH : 0);
+#pragma unroll
+            for (int i = 0; i < PERH; ++i) k[i] = wload(u, (unsigned)c.g.lane * 16u, i);
+        };
+        if constexpr (P8) park(k8, L(ap->dec1));
+        if constexpr (P9) park(k9, L(ap->dec2));
+        if constexpr (P12) park(k12, L(ap->px1));
+        if constexpr (P13) park(k13, L(ap->px2));
     }
     {
         const FlowLin first = ENCODE ? L(ap->enc0h) : L(ap->dec0h);
         const GPtr ub = uniform_ptr(first.w, hfull ? (size_t)c.g.ntile * first.wnb + c.g.wave * PERH : 0);
 #pragma unroll
         for (int u = 0; u < PERH; ++u) wa[u] = wload(ub, (unsigned)c.g.lane * 16u, u);
+        if constexpr (PL) {
+#pragma unroll
+            for (int u = 0; u < PERH; ++u) c.lpark[u * 64 + c.g.lane] = __builtin_bit_cast(u32x4, wa[u]);      // (read back by this very wave only)
+        }
     }
     for (long long t = 0; t < T; ++t) {
+        if constexpr (PL) {                                // the first layer's weights come out of LDS (requested by nobody)
+#pragma unroll
+            for (int u = 0; u < PERH; ++u) wa[u] = __builtin_bit_cast(f32x4, c.lpark[u * 64 + c.g.lane]);
+        }
         asm volatile("" : "+s"(ap));                       // see FlowArgsC
         c.a = ap;
         const auto &a = *ap;
@@ -1086,6 +1198,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
         const FlowFill f_hh = {a.w_hh, hb, hb, hsrc}, f_d0 = {a.dec0h.w, a.dec0h.wnb, hb, hsrc}, f_iz = {a.w_ihz, 2 * hb, hb, zsrc};
         const bool folded = FOLD < 0 ? a.pxc.w != nullptr : FOLD == 1;      // (uniform) dec.6 -> norm -> phi_x.0 folded into one layer (FlowArgs::pxc)
         if constexpr (!MULTI) {
+            // (wK: the weights of wide layer K - prefetched into wa / wb by the layer in front of it, or resident in registers: P8 .. P13)
+            auto &w8 = pick<P8>(k8, wb);  auto &w9 = pick<P9>(k9, wa);  auto &w12 = pick<P12>(k12, wa);  auto &w13 = pick<P13>(k13, wb);
             if (ENCODE) {
                 //         PER   epilogue  two    add    pre_in pre_out       rearm  filler
                 flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 1, L(a.enc0h), FB_H, L(a.enc0h), 0, hb, hb, FB_E1, wa, L(a.enc1), wb, gq, zero4, f_hh, &c.fgh[0]);
@@ -1097,34 +1211,34 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                     FlowLin d0 = L(a.dec0z);                   // dec.0: only the phi_z half is left; the bias travels with dec0h
                     d0.bias = a.dec0h.bias;
                     flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, d0, wa, gq);
-                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G0, NW>(c, 7, d0, FB_Q3, d0, 0, hb, hb, FB_D1, wa, L(a.dec1), wb, gq, c.fd0, f_iz, &c.fgi[0]);
+                    flow_layer<PERH, FE_ELU, false, false, true, !P8, PERH, false, G0, NW>(c, 7, d0, FB_Q3, d0, 0, hb, hb, FB_D1, wa, L(a.dec1), wb, gq, c.fd0, f_iz, &c.fgi[0]);
                 } else {
                     flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 6, L(a.pz2), FB_Q2, L(a.pz2), 0, hb, hb, FB_Q3, wb, L(a.dec0h), wa, gq);
                     flow_layer<PERH, FE_ELU, true, false, true, true, PERH, false, -2, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0z), FB_Q3, hb, hb, FB_D1, wa, L(a.dec1), wb, gq);
                 }
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, gq, zero4, f_iz, &c.fgi[1]);
+                flow_layer<PERH, FE_ELU, false, false, true, !P9, PERH, false, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, w8, L(a.dec2), wa, gq, zero4, f_iz, &c.fgi[1]);
                 if (folded) {
-                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.pxc), wb, gq, zero4, f_iz, &c.fgi[2]);
-                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 11, L(a.pxc), FB_D3, L(a.pxc), 0, hb, hb, FB_G1, wb, L(a.px1), wa, gq);
+                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, w9, L(a.pxc), wb, gq, zero4, f_iz, &c.fgi[2]);
+                    flow_layer<PERH, FE_ELU, false, false, true, !P12, PERH, false, -2, NW>(c, 11, L(a.pxc), FB_D3, L(a.pxc), 0, hb, hb, FB_G1, wb, L(a.px1), wa, gq);
                 } else {
-                    flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, gq, zero4, f_iz, &c.fgi[2]);
+                    flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, w9, L(a.dec2), wb, gq, zero4, f_iz, &c.fgi[2]);
                     flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb, gq);
                 }
             } else {
-                flow_layer<PERH, FE_ELU, false, true, true, true, PERH, false, G0, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, gq, zero4, f_hh, &c.fgh[0]);
-                flow_layer<PERH, FE_ELU, false, false, true, true, PERH, true, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, wb, L(a.dec2), wa, gq, zero4, f_hh, &c.fgh[1]);
+                flow_layer<PERH, FE_ELU, false, true, true, !P8, PERH, false, G0, NW>(c, 7, L(a.dec0h), FB_H, L(a.dec0h), 0, hb, hb, FB_D1, wa, L(a.dec1), wb, gq, zero4, f_hh, &c.fgh[0]);
+                flow_layer<PERH, FE_ELU, false, false, true, !P9, PERH, true, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, w8, L(a.dec2), wa, gq, zero4, f_hh, &c.fgh[1]);
                 if (folded) {                              // dec.4 (its output is kept for all frames) -> phi_x.0 o norm o dec.6 as one wide layer
-                    flow_layer<PERH, FE_ELU_KEEP, false, false, true, true, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.pxc), wb, gq, zero4, f_hh, &c.fgh[2]);
-                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 11, L(a.pxc), FB_D3, L(a.pxc), 0, hb, hb, FB_G1, wb, L(a.px1), wa, gq);
+                    flow_layer<PERH, FE_ELU_KEEP, false, false, true, true, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, w9, L(a.pxc), wb, gq, zero4, f_hh, &c.fgh[2]);
+                    flow_layer<PERH, FE_ELU, false, false, true, !P12, PERH, false, -2, NW>(c, 11, L(a.pxc), FB_D3, L(a.pxc), 0, hb, hb, FB_G1, wb, L(a.px1), wa, gq);
                 } else {
-                    flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, wa, L(a.dec2), wb, gq, zero4, f_hh, &c.fgh[2]);
+                    flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, w9, L(a.dec2), wb, gq, zero4, f_hh, &c.fgh[2]);
                     flow_layer<PERH, FE_MEL, false, false, false, false, PERH, false, -2, NW>(c, 10, L(a.dec3), FB_D3, L(a.dec3), 0, hb, xb, FB_DN, wa, L(a.dec3), wb, gq);
                 }
             }
             if (!folded)
-                flow_layer<1, FE_ELU, false, false, false, true, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa, gq);
-            flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, -2, NW>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, wa, L(a.px2), wb, gq);
-            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, -2, NW, GFAST>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, wb, L(a.px2), wa, gq);
+                flow_layer<1, FE_ELU, false, false, false, !P12, PERH, false, -2, NW>(c, 11, L(a.px0), FB_DN, L(a.px0), 0, xb, hb, FB_G1, w1, L(a.px1), wa, gq);
+            flow_layer<PERH, FE_ELU, false, false, true, !P13, PERH, false, -2, NW>(c, 12, L(a.px1), FB_G1, L(a.px1), 0, hb, hb, FB_G2, w12, L(a.px2), wb, gq);
+            flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, -2, NW, GPRE>(c, 13, L(a.px2), FB_G2, L(a.px2), 0, hb, hb, FB_G3, w13, L(a.px2), wa, gq);
             flow_gru<PERH, ENCODE, PERH, FILL, NW>(c, 14, hb, ENCODE ? L(a.enc0h) : L(a.dec0h), wa, gq);
         } else {
             // the same program on interleaved chains (no filler quanta): wide single-segment layers pipeline their chains
@@ -1208,7 +1322,7 @@ int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s) {
 constexpr size_t flow_lds(int nw) { return (size_t)(2 * nw * 256 + nw * 6 * 256) * sizeof(float); }      // 64 KiB with 8 waves
 constexpr size_t FLOW_LDS = flow_lds(8);
 constexpr size_t FLOW_LDS_MULTI = FLOW_LDS + (size_t)2 * 4 * 8 * 256 * sizeof(float);  // + two slots of four chains' partial tiles: 128 KiB
-constexpr size_t FLOW_LDS_FILL = (size_t)(2 * 8 * 256 + 8 * 8 * 256 + 8 * 6 * 256) * sizeof(float) + 16;       // partials | stashes (over the GRU partials) | parked GRU weights | flag: 128 KiB
+constexpr size_t FLOW_LDS_FILL = (size_t)(2 * 8 * 256 + 8 * 8 * 256 + 8 * 8 * 256) * sizeof(float) + 16;       // partials | stashes (over the GRU partials) | parked weights | flag: 144 KiB
 
 template <int PERH, bool ENC>
 static int flow_attr() {
