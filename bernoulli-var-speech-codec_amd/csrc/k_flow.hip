@@ -20,6 +20,12 @@
 // Every wait is bounded: a wave that waits too long records it in the model's status word and stops
 // waiting for good (results are then garbage, the kernel still ends) - bvc_model_status() reports it.
 //
+// What sits in a compute unit for the whole launch (filler form, h_dim 1024): the weights of two wide layers (decode: three) in registers -
+// the kernel needs 165 of the 256 VGPRs a wave may have - and the first layer's in the 64 KiB of LDS the kernel had left; the vector
+// instructions on a hop's critical path are few on purpose (fp32 MFMAs and vector instructions share the ALUs, also within one wave:
+// profiles/r04_mfma_valu_overlap.txt), and scheduling fences keep loads and checks where the source puts them (hipcc sinks loads to their
+// first use and hoists checks in front of the products when left alone: profiles/r04_flow_variants.txt).
+//
 // Measured form of the hand-off: MI355X_MICROARCH.md (valid forms: sc1 stores, sc1 loads, data-tagged
 // granules), tools/persist_bench.hip (3.3-3.8 us per 1024x1024 layer against 4.25 launch-per-layer).
 #include "bvc_internal.h"
@@ -79,12 +85,10 @@ namespace {
 #ifndef BVC_GRU_FAST
 #define BVC_GRU_FAST 0
 #endif
+//   (what round 4 measured and did not keep - resident rounds of the GRU stream, other request orders, fences in the chain kernels - is in
+//   profiles/r04_flow_variants.txt)
 //   BVC_GRU_FENCE         1 (default): scheduling fences around the rounds of the GRU layer's weight stream (see flow_gru)
 //   BVC_GRU_DEPTH         register sets the stream runs through (default 3; 2: the request for round i + 1 in front of round i's products; up to all four rounds)
-//   BVC_GRU_PRE           1: (h_dim 1024, filler form) round 0 of the GRU layer's weight stream is requested by the layer in front of it, phi_x.4,
-//                         in front of ITS reduction barrier - where every other layer requests its successor's weights -, round 1 at the GRU
-//                         layer's entry, rounds 2 and 3 behind the operand fetch.  Whatever a wave requests at the entry returns, in order,
-//                         BEFORE its flag poll: two rounds there (96 KiB per compute unit) held the polls back for 1.7 us
 //   BVC_FLOW_PARKV        2 (default; 0 off, 1 two layers): (filler form) the weights of two wide layers (three in decode) - this wave's 8 blocks each - stay in registers for the whole launch
 //                         (the filler kernels use 165 of the 256 VGPRs a wave may have): 128 KiB per compute unit and frame less to pull from
 //                         the L2, whose fill path into the compute units is what the kernel is bound by
@@ -99,12 +103,6 @@ namespace {
 #endif
 #ifndef BVC_FLOW_PARK_SET
 #define BVC_FLOW_PARK_SET 1                          // which two: 1 dec.2 + dec.4, 0 phi_x.2 + phi_x.4
-#endif
-#ifndef BVC_GRU_PRE
-#define BVC_GRU_PRE 0
-#endif
-#ifndef BVC_GRU_FENCE_CHAINS
-#define BVC_GRU_FENCE_CHAINS 0                       // the same fences in flow_gru_chains (batches beyond 64 utterances)
 #endif
 #ifndef BVC_GRU_FENCE
 #define BVC_GRU_FENCE 1
@@ -540,7 +538,7 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
             fill_issue<PERN, FGATE>(g, fill, fw, fx);
             fill_multiply<PERN, FGATE>(g, fill, fw, fx, *facc, c.stash);
         }
-        if ((BVC_GRU_FAST || BVC_GRU_PRE) && GRUPRE) {
+        if (BVC_GRU_FAST && GRUPRE) {
 #pragma unroll
             for (int i = 0; i < GRU_EARLY_BLOCKS; ++i) gq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};     // defined on every path (see wn)
         }
@@ -605,11 +603,6 @@ __device__ __forceinline__ void flow_layer(FlowCtx &c, int hopid, const FlowLin 
         const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
         for (int u = 0; u < PERN; ++u) wn[u] = wload(ub, (unsigned)lane * 16u, u);
-    }
-    if (BVC_GRU_PRE && !BVC_GRU_FAST && GRUPRE) {          // round 0 of the GRU layer's weights (two k-blocks x three gates)
-        const GPtr ug = uniform_ptr(a.w_ihx, ((size_t)g.ntile * 2 * a.hb + wave * PER) * 3 * g.wmul);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) gq[i] = wload(ug, (unsigned)lane * 16u, i);
     }
     // The quantum's operands are requested in front of the barrier and multiplied behind it.  (Round 2 measured the other orders with
     // the quantum's input re-fetched from memory: the publishing wave requesting its own behind its store, or every wave behind the
@@ -912,32 +905,6 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
         gru_round6<PER>(gq + 6, xa, 4, gi);
         gru_round6<PER>(gq, xa, 6, gi);
         __builtin_amdgcn_sched_barrier(0);
-    } else if constexpr (FILL && PER == 8 && BVC_GRU_PRE) {
-        // four rounds of two k-blocks x three gates, in k order (the sums of the generic form below).  Round 0 has been on its way since
-        // phi_x.4's reduction barrier (gq[0..5]); round 1 is requested now, rounds 2 and 3 only behind the operand fetch.
-        const unsigned l16 = (unsigned)lane * 16u;
-        const GPtr ux = uniform_ptr(a.w_ihx, ((size_t)g.ntile * 2 * hb + wave * PER) * 3 * g.wmul);
-        u32x4 xa[PER];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) gq[6 + i] = wload(ux, l16, 6 + i);                    // round 1
-        __builtin_amdgcn_sched_barrier(0);
-        gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * c.sb, hb, xa, c.give_up, code);
-        if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 2);
-        f32x4 g2[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) g2[i] = wload(ux, l16, 12 + i);                       // round 2
-        __builtin_amdgcn_sched_barrier(0);
-        gru_round6<PER>(gq, xa, 0, gi);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) gq[i] = wload(ux, l16, 18 + i);                       // round 3 into round 0's registers
-        __builtin_amdgcn_sched_barrier(0);
-        gru_round6<PER>(gq + 6, xa, 2, gi);
-        __builtin_amdgcn_sched_barrier(0);
-        gru_round6<PER>(g2, xa, 4, gi);
-        __builtin_amdgcn_sched_barrier(0);
-        gru_round6<PER>(gq, xa, 6, gi);
-        __builtin_amdgcn_sched_barrier(0);
     } else if (!(PER == 1 && wave >= hb)) {                // (wave-uniform) a wave without a k-block of its own contributes zeros
         constexpr int HALF = FILL ? (PER >= BVC_GRU_ROUNDS_FILL ? PER / BVC_GRU_ROUNDS_FILL : 1) : (PER >= 4 ? PER / 4 : 1);       // k-blocks per round
         constexpr int RPS = PER / HALF;                    // rounds per segment
@@ -966,8 +933,8 @@ __device__ __forceinline__ void flow_gru(FlowCtx &c, int hopid, int hb, const Fl
             const int sg = i / RPS, h0 = (i % RPS) * HALF;
             if (i + DEPTH - 1 < NR) gru_issue_w<HALF>(wsrc(i + DEPTH - 1), l16, ((i + DEPTH - 1) % RPS) * HALF, wr[(i + DEPTH - 1) % DEPTH]);
             if (BVC_GRU_FENCE) __builtin_amdgcn_sched_barrier(0);
-            if (i == (NSEG - 1) * RPS) {                   // the last segment's input, phi_x(d_t): wait, fetch, verify
-                gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * c.sb, hb, xa, c.give_up, code);
+            if (i == (NSEG - 1) * RPS) {                   // the last segment's input, phi_x(d_t): wait, fetch, verify.  (What was requested in front
+                gru_fetch_fresh<PER>(g, (unsigned)(FB_G3 * 2 + c.par) * c.sb, hb, xa, c.give_up, code);     // of the poll travels during the wait.)
                 if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 2);        // (here: flags seen AND operands fetched)
             }
             if (FILL)                   gru_round<PER, HALF>(wr[i % DEPTH], xa, h0, gi);
@@ -1028,7 +995,6 @@ __device__ __forceinline__ void flow_gru_chains(FlowCtx &c, int hopid, int hb, c
                 const int sn = (i + 1) / RPS, hn0 = ((i + 1) % RPS) * HALF;
                 gru_issue_w<HALF>(sn == 0 ? uh : ((ENCODE && sn == 1) ? uz : ux), l16, hn0, wr[(i + 1) & 1]);
             }
-            if (BVC_GRU_FENCE_CHAINS) __builtin_amdgcn_sched_barrier(0);       // (the request for round i + 1 really in front of round i's products: see flow_gru)
             // a chain's operand blocks of the NEXT segment are requested as soon as its last round of this one is multiplied: they
             // travel under the partner's round (phi_x(d_t), produced last, is waited for, fetched and verified; h and phi_z are known)
             const bool seg_end = (i % RPS == RPS - 1) && i + 1 < NR;
@@ -1047,7 +1013,6 @@ __device__ __forceinline__ void flow_gru_chains(FlowCtx &c, int hopid, int hb, c
                 if (next_fresh) { if (two) gru_fetch_fresh<PER>(gB, (unsigned)(FB_G3 * 2 + c.par) * c.sb, hb, xB, c.give_up, code); }
                 else            gru_issue_known<PER>(gB, (unsigned)(FB_Q3 * 2 + c.par) * c.sb, hb, xB);
             }
-            if (BVC_GRU_FENCE_CHAINS) __builtin_amdgcn_sched_barrier(0);
         }
         // the two cells' epilogues, one after the other (one set of partial tiles in LDS)
         for (int k = 0; k < (two ? 2 : 1); ++k) {
@@ -1138,7 +1103,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     f32x4 wa[PERH], wb[PERH], w1[1];
     f32x4 gq[GRU_EARLY_BLOCKS];                            // BVC_GRU_FAST: the GRU layer's early-requested weights (rounds 0, 1)
     constexpr bool GFAST = FILL && PERH == 8 && BVC_GRU_FAST && !MULTI;
-    constexpr bool GPRE = FILL && PERH == 8 && (BVC_GRU_FAST || BVC_GRU_PRE) && !MULTI;    // phi_x.4 requests GRU weights early
+    constexpr bool GPRE = GFAST;
     if (GFAST && hfull) {                                  // park round 2 (k-blocks 4, 5 x three gates) of this wave's share of W_ih[:, :H]
         const GPtr ux = uniform_ptr(ap->w_ihx, (((size_t)c.g.ntile * 2 * hb + c.g.wave * PERH) * 3 + 12) * c.g.wmul);
 #pragma unroll

@@ -41,6 +41,12 @@ __device__ __forceinline__ void divide_if(bool div, f32x4 &v, float d) {
     }
 }
 
+// tile index -> (batch item, tile of the item): the quotient by a run-time divisor through a host-made reciprocal (one scalar multiply-high)
+// instead of hipcc's float-reciprocal emulation of the 32-bit division - some forty vector instructions, per tile and wave in the persistent
+// kernels.  Exact while bid * tiles_per_batch < 2^32 (launch_* check it).
+__device__ __forceinline__ unsigned div_tpb(unsigned bid, unsigned tpb_magic) { return __umulhi(bid, tpb_magic); }
+static inline unsigned tpb_magic_of(unsigned d) { return d <= 1u ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / d) + 1u; }      // (d == 1: q = bid handled by the callers)
+
 struct ConvArgs {
     const float *in;  long long Lin;
     float *out;       long long Lout;
@@ -232,6 +238,7 @@ struct AmpArgs {
     const float *w2, *b2, *a2, *ib2;
     float divisor;
     int epi, ks, dil, tiles_per_batch;
+    unsigned tpb_magic;           // tpb_magic_of(tiles_per_batch)
     unsigned ntile;               // workgroups that have a tile (grid is padded to a multiple of 8)
     long long bs;                 // floats between batch items of x / out / acc
     long long row_begin;          // first output row (streaming: rows before it are history)
@@ -278,8 +285,8 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
     const unsigned nwg = gridDim.x, per = (nwg + 7u) >> 3;
     unsigned bid = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     if (bid >= a.ntile) return;                           // grid is padded to a multiple of 8
-    const int b = bid / a.tiles_per_batch;
-    const long long t0 = a.row_begin + (long long)(bid % a.tiles_per_batch) * TT;
+    const int b = a.tiles_per_batch == 1 ? (int)bid : (int)div_tpb(bid, a.tpb_magic);
+    const long long t0 = a.row_begin + (long long)(bid - (unsigned)b * (unsigned)a.tiles_per_batch) * TT;
     const int halo1 = (ks - 1) * dil;
     const int rows1 = TR + halo1;                          // S1(x) rows [t0-(ks-1)-halo1, t0-(ks-1)+TR)
     float *t1 = lds;
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(256, OCC) void amp_pair8_kernel(AmpArgs a) {
     const f32x4 bb2 = *reinterpret_cast<const f32x4 *>(a.ib2 + co0), bias2 = *reinterpret_cast<const f32x4 *>(a.b2 + co0);
 
     auto tile_origin = [&](unsigned bid, int &b, long long &t0) {
-        b = (int)(bid / (unsigned)a.tiles_per_batch);
+        b = a.tiles_per_batch == 1 ? (int)bid : (int)div_tpb(bid, a.tpb_magic);
         t0 = a.row_begin + (long long)(bid - (unsigned)b * (unsigned)a.tiles_per_batch) * TT;
     };
     auto load_rows = [&](unsigned bid, f32x4 (&v)[NLD]) {       // x rows [t0 - (KS-1) - HALO1, .. + ROWS1) of tile bid
@@ -799,6 +806,8 @@ static int launch_amp8_t(AmpArgs a, int B, hipStream_t s) {
     using G = Amp8Geom<KS, D, MT2>;
     a.tiles_per_batch = (int)((a.L - a.row_begin + G::TT - 1) / G::TT);
     if (a.tiles_per_batch <= 0) return BVC_OK;
+    a.tpb_magic = tpb_magic_of((unsigned)a.tiles_per_batch);
+    if ((unsigned long long)a.tiles_per_batch * a.tiles_per_batch * (unsigned long long)B >= 0x100000000ull) { set_error("vocoder: tile count beyond the reciprocal's range"); return BVC_EINVAL; }
     const int slots = amp8_slots<KS, D, MT2, OCC>();
     if (slots <= 0) return BVC_EHIP;
     ProbeScope probe(PK_CONV, s);
@@ -878,7 +887,7 @@ __global__ __launch_bounds__(256, OCC) void amp_pair16_kernel(AmpArgs a) {
     for (int idx = tid; idx < (KS - 1) * S; idx += 256) t2[TR * S + idx] = 0.0f;     // spare rows: never written again
 
     auto tile_origin = [&](unsigned bid, int &b, long long &t0) {
-        b = (int)(bid / (unsigned)a.tiles_per_batch);
+        b = a.tiles_per_batch == 1 ? (int)bid : (int)div_tpb(bid, a.tpb_magic);
         t0 = a.row_begin + (long long)(bid - (unsigned)b * (unsigned)a.tiles_per_batch) * TT;
     };
     auto load_rows = [&](unsigned bid, f32x4 (&v)[NLD]) {       // x rows [t0 - (KS-1) - HALO1, .. + ROWS1) of tile bid
@@ -1011,6 +1020,8 @@ static int launch_amp16_t(AmpArgs a, int B, hipStream_t s) {
     using G = Amp16Geom<KS, D, MT>;
     a.tiles_per_batch = (int)((a.L - a.row_begin + G::TT - 1) / G::TT);
     if (a.tiles_per_batch <= 0) return BVC_OK;
+    a.tpb_magic = tpb_magic_of((unsigned)a.tiles_per_batch);
+    if ((unsigned long long)a.tiles_per_batch * a.tiles_per_batch * (unsigned long long)B >= 0x100000000ull) { set_error("vocoder: tile count beyond the reciprocal's range"); return BVC_EINVAL; }
     const int slots = amp16_slots<KS, D, MT, OCC>();
     if (slots <= 0) return BVC_EHIP;
     ProbeScope probe(PK_CONV, s);
@@ -1052,6 +1063,8 @@ static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
     const int TT = TR - (a.ks - 1);
     a.tiles_per_batch = (int)((a.L - a.row_begin + TT - 1) / TT);
     if (a.tiles_per_batch <= 0) return BVC_OK;
+    a.tpb_magic = tpb_magic_of((unsigned)a.tiles_per_batch);
+    if ((unsigned long long)a.tiles_per_batch * a.tiles_per_batch * (unsigned long long)B >= 0x100000000ull) { set_error("vocoder: tile count beyond the reciprocal's range"); return BVC_EINVAL; }
     const size_t lds = (size_t)((TR + (a.ks - 1) * a.dil) + (ALIAS ? 0 : TR + (a.ks - 1))) * (C + 2) * sizeof(float);
     if (lds > 160 * 1024 || TT <= 0) { set_error("amp_pair tile needs %zu B of LDS", lds); return BVC_EINVAL; }
     ProbeScope probe(PK_CONV, s);
