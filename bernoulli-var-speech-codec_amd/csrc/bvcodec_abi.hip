@@ -1314,7 +1314,6 @@ int run_encode_body(const bvc_model *m, const Workspace &w, void *ws_base, const
     const long long BT = (long long)B * T;
     int rc;
     if (m->cfg.var_bit && !d_bits) { set_error("bits per frame required when var_bit=1"); return BVC_EINVAL; }
-    if (m->side_branch) { set_error("BVC_SIDE_BRANCH: the side-branch experiment of round 1 is no longer wired into encode"); return BVC_EINVAL; }
     // y = (y - mean) / std ; phi_x over all frames (bvrnn.py:173-178)
     if ((rc = launch_normalize_rows(d_mel, m->mean_mel, m->std_mel, BT, X, w.yn, s))) return rc;
     const int chains = flow_chains(m, B, s);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The bench lines of a round (run on the GPU box from the repository root): gpurun -- 'bash tools/bench_round.sh r03'
 set -eo pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/bench_$TAG
 mkdir -p $OUT
 python bench.py > $OUT/${TAG}_a_bench_default.json 2> $OUT/a.err

@@ -4,7 +4,7 @@
 #   so they never share a run with the timing) on tools/pmc_probe.py = one 64 x 5 s encode + decode.
 # Results land in gpurun_out/; copy the summaries you want judged into profiles/.
 set -eo pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
