@@ -2304,11 +2304,15 @@ int bvc_kprobe_read_span(int32_t from, int32_t to, int32_t node_lo, int32_t node
         BVC_HIP_TRY(hipMemcpy(h.data(), g_kprobe.dev, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         for (long long t = 0; t < g_kprobe.T; ++t)
             for (int k = node_lo; k < node_hi && k < g_kprobe.nodes; ++k) {
-                unsigned long long a;
+                unsigned long long a = 0;
                 if (from >= 0) a = h[(size_t)from * per + t * g_kprobe.nodes + k];
-                else if (k > 0) a = h[per + t * g_kprobe.nodes + k - 1];
-                else if (t > 0) a = h[per + (t - 1) * g_kprobe.nodes + g_kprobe.nodes - 1];
-                else continue;
+                else {
+                    // from the previous layer's "published" stamp: the nearest earlier node that was stamped at all (with the folded hop the
+                    // program has no dec.6 node: its slot stays empty), wrapping into the previous frame's last layer
+                    long long idx = t * g_kprobe.nodes + k - 1;
+                    for (int back = 0; back < g_kprobe.nodes && idx >= 0 && !a; ++back, --idx) a = h[per + idx];
+                    if (!a) continue;
+                }
                 const unsigned long long b = h[(size_t)to * per + t * g_kprobe.nodes + k];
                 if (!a || b <= a) continue;
                 const double us = (double)(b - a) * 0.01;        // 100 MHz ticks

@@ -298,7 +298,8 @@ int bvc_kprobe_read(int32_t node_lo, int32_t node_hi, double *mean_us, double *m
 /* Persistent recurrence only: one wave (workgroup BVC_PROBE_WG, wave BVC_PROBE_WAVE; default 0 / 0) stamps per layer and frame:
  * 0 layer entered, 1 output published; a library built with -DBVC_FLOW_DIAG=1 also 2 flags seen, 3 products done, 4 reduction
  * barrier passed, 5 layer left.  Mean / min of (stamp `to` - stamp `from`) over the frames of the LAST call for the layers
- * [node_lo, node_hi); from = -1 measures from the previous layer's stamp 1. */
+ * [node_lo, node_hi); from = -1 measures from the stamp 1 of the nearest earlier layer that ran (with the folded hop the program has no dec.6
+ * node: its slot stays empty and its row reads 0). */
 int bvc_kprobe_read_span(int32_t from, int32_t to, int32_t node_lo, int32_t node_hi, double *mean_us, double *min_us,
                          int32_t *n_samples);
 
