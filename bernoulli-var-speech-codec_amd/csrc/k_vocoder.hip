@@ -47,6 +47,16 @@ __device__ __forceinline__ void divide_if(bool div, f32x4 &v, float d) {
 __device__ __forceinline__ unsigned div_tpb(unsigned bid, unsigned tpb_magic) { return __umulhi(bid, tpb_magic); }
 static inline unsigned tpb_magic_of(unsigned d) { return d <= 1u ? 0xFFFFFFFFu : (unsigned)(0x100000000ull / d) + 1u; }      // (d == 1: q = bid handled by the callers)
 
+// Rows of a channels-last (L, C) signal through a BUFFER descriptor of exactly L * C floats: a row before the start or behind the end of the
+// signal is out of the descriptor's range and reads as zeros by itself (also a negative row: its byte offset wraps to a huge unsigned one) -
+// no clamping, no compare, no select per item (a third of the vector instructions the tile loads of these kernels issued beside SnakeBeta).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const float *base, long long L, int C) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(L * C * 4), 0x00020000);
+}
+__device__ __forceinline__ f32x4 rows_load4(__amdgpu_buffer_rsrc_t rs, int row, int C, int c0) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (row * C + c0) * 4, 0, 0));
+}
+
 struct ConvArgs {
     const float *in;  long long Lin;
     float *out;       long long Lout;
@@ -303,21 +313,17 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
         // made hipcc wait `vmcnt(0)` behind every other one - five exposed round trips per tile at C = 32 instead of one.
         f32x4 v[NLD];
         const int total = rows1 * C4;
-        unsigned okmask = 0u;
+        const __amdgpu_buffer_rsrc_t rs = rows_rsrc(xb, a.L, C);       // rows outside the signal read as zeros (rows_load4)
+        const int tfirst = (int)(tbase - halo1);
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + i * 256;
             const int row = idx / C4, c4 = idx - row * C4;
-            const long long tg = tbase - halo1 + row;
-            const bool ok = idx < total && tg >= 0 && tg < a.L;
-            const long long tgc = tg < 0 ? 0 : (tg < a.L ? tg : a.L - 1);
-            v[i] = *reinterpret_cast<const f32x4 *>(xb + tgc * C + c4 * 4);
-            okmask |= (ok ? 1u : 0u) << i;
+            v[i] = rows_load4(rs, tfirst + row, C, c4 * 4);
         }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + i * 256;
-            if (!((okmask >> i) & 1u)) v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (idx < total) {
                 const int row = idx / C4, c4 = idx - row * C4;
                 const f32x4 aa = *reinterpret_cast<const f32x4 *>(a.a1 + c4 * 4);
@@ -644,14 +650,12 @@ __global__ __launch_bounds__(256, OCC) void amp_pair8_kernel(AmpArgs a) {
     auto load_rows = [&](unsigned bid, f32x4 (&v)[NLD]) {       // x rows [t0 - (KS-1) - HALO1, .. + ROWS1) of tile bid
         int b; long long t0;
         tile_origin(bid, b, t0);
-        const float *xb = a.x + (long long)b * a.bs;
-        const long long tfirst = t0 - (KS - 1) - G::HALO1;
+        const __amdgpu_buffer_rsrc_t rs = rows_rsrc(a.x + (long long)b * a.bs, a.L, C);
+        const int tfirst = (int)(t0 - (KS - 1) - G::HALO1);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
+        for (int i = 0; i < NLD; ++i) {                        // (items past the tile's rows: loaded like the others, never parked)
             const int idx = tid + i * 256;
-            const long long tg = tfirst + (idx >> 1);
-            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (idx < G::ROWS1 * 2 && tg >= 0 && tg < a.L) v[i] = *reinterpret_cast<const f32x4 *>(xb + tg * C + (idx & 1) * 4);
+            v[i] = rows_load4(rs, tfirst + (idx >> 1), C, (idx & 1) * 4);
         }
     };
 
@@ -893,14 +897,12 @@ __global__ __launch_bounds__(256, OCC) void amp_pair16_kernel(AmpArgs a) {
     auto load_rows = [&](unsigned bid, f32x4 (&v)[NLD]) {       // x rows [t0 - (KS-1) - HALO1, .. + ROWS1) of tile bid
         int b; long long t0;
         tile_origin(bid, b, t0);
-        const float *xb = a.x + (long long)b * a.bs;
-        const long long tfirst = t0 - (KS - 1) - G::HALO1;
+        const __amdgpu_buffer_rsrc_t rs = rows_rsrc(a.x + (long long)b * a.bs, a.L, C);
+        const int tfirst = (int)(t0 - (KS - 1) - G::HALO1);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
+        for (int i = 0; i < NLD; ++i) {                        // (items past the tile's rows: loaded like the others, never parked)
             const int idx = tid + i * 256;
-            const long long tg = tfirst + (idx >> 2);
-            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (idx < G::ROWS1 * C4 && tg >= 0 && tg < a.L) v[i] = *reinterpret_cast<const f32x4 *>(xb + tg * C + (idx & 3) * 4);
+            v[i] = rows_load4(rs, tfirst + (idx >> 2), C, (idx & 3) * 4);
         }
     };
 
