@@ -21,6 +21,7 @@ one stream.  Rank 0 prints ONE JSON line: metric/value (audio-seconds coded per 
   multi_stream  - the same K steps issued round-robin on four HIP streams (4 x 64 utterances in flight); the library's
                   default recurrence schedule ("auto") switches to the launch-per-layer kernels by itself there
   gather_ms     - mean duration of the per-step RCCL all-gather (HIP event pair on its stream; 0 without a process group)
+  forward_fused - forward(x, bitrate) with ONE recurrence (bvc_forward; clearly NOT the headline, which stays encode() + decode())
   target_workload / encode_only / streaming - BASELINE configs[3]'s per-GPU shard (64 x 10 s, the north-star target's
                   utterance length; bitrates 1.5 / 3 / 6 kbit/s; with --gpus N > 1 EVERY rank runs its shard, the per-step
                   all-gather included, max over ranks), configs[2] (encode only) and configs[4] (256 streams x 20 ms hops,
@@ -342,6 +343,24 @@ def leg_target_workload(conf, model, device, B, bitrate, with_parity, steps=5, w
     return out
 
 
+def leg_forward_fused(conf, model, device, x, bitrate, with_parity, steps=5):
+    """NOT the headline and not a BASELINE config: BVRNNCodecModel.forward(x, bitrate) (bvrnn_codec_model.py:73-76, example.py:20) on the
+    benchmark's batch through bvc_forward - the encoder's frame loop already runs the decoder on every frame, so its outputs go to
+    the vocoder and the second recurrence (and the all-frame phi_z GEMMs) of decode(encode(x)) are not run again."""
+    B, L = x.shape
+    model.forward_fused(x, bitrate)
+    dt, wav = time_steps(lambda: model.forward_fused(x, bitrate), steps, device)
+    model.check_status()
+    out = {"workload": f"forward(x, {bitrate:g}) on batch {B} x {L / FS:g} s through bvc_forward (one recurrence; the headline stays encode() + decode())",
+           "value": round(B * (L / FS) * steps / dt, 2), "unit": "audio-seconds/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps}
+    if with_parity:                # the oracle's forward() = decode(encode(x)) on two utterances
+        oc = get_oracle(conf)
+        ref = oc.forward(x[:2].cpu(), bitrate)
+        out["parity"] = {"waveform_rms_error_vs_oracle_forward": float((wav[:2].cpu() - ref).pow(2).mean().sqrt()),
+                         "waveform_rms": float(ref.pow(2).mean().sqrt()), "utterances_checked": [0, 1]}
+    return out
+
+
 def leg_large_batch(conf, model, device, bitrate, with_parity, B=256, steps=3):
     """Not a BASELINE config: 256 x 5 s in ONE call, the persistent recurrence on interleaved chains (four utterance groups per
     workgroup) - what a caller gets who can batch more than 64 utterances."""
@@ -440,7 +459,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the target_workload / encode_only / streaming / large_batch legs")
-    ap.add_argument("--legs", default="target,encode,streaming,large", help="which of the extra legs run (comma separated)")
+    ap.add_argument("--legs", default="target,encode,fused,streaming,large", help="which of the extra legs run (comma separated)")
     a = ap.parse_args()
 
     # RCCL prints a version banner on STDOUT when its communicator is created; this program's stdout is one JSON line, so
@@ -655,6 +674,9 @@ def main():
         if "encode" in legs:
             out["encode_only"] = leg_encode_only(conf, model, device, x, a.bitrate, codes)
             note("encode_only done")
+        if "fused" in legs:
+            out["forward_fused"] = leg_forward_fused(conf, model, device, x, a.bitrate, with_par)
+            note("forward_fused done")
         if "streaming" in legs:
             out["streaming"] = leg_streaming(conf, model, device, a.bitrate, with_par)
             note("streaming done")

@@ -64,6 +64,7 @@ SIGNATURES = {
     "bvc_stream_codec_tick": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), _vp]),
     "bvc_encode": (ctypes.c_int, [_vp, _vp, _i32, _i64, _f, _f, _vp, _vp, _sz, _vp]),
     "bvc_decode": (ctypes.c_int, [_vp, _vp, _i32, _i64, _i64, _f, _vp, _vp, _sz, _vp]),
+    "bvc_forward": (ctypes.c_int, [_vp, _vp, _i32, _i64, _f, _f, _i64, _f, _vp, _vp, _vp, _sz, _vp]),
     "bvc_resample_poly": (ctypes.c_int, [_vp, _i32, _i64, _vp, _i32, _i32, _i32, _i64, _vp, _i64, _vp]),
     "bvc_peak_normalize": (ctypes.c_int, [_vp, _i32, _i64, _vp]),
     "bvc_pack_codes": (ctypes.c_int, [_vp, _i32, _i64, _i32, _i32, _vp, _vp]),

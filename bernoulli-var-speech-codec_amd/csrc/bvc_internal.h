@@ -38,7 +38,8 @@ struct ProbeScope {
 enum DescSlot { DS_PX = 0, DS_CODES = 1, DS_BITS = 2, DS_PROB = 3, DS_ALLH = 4, DS_MEL = 5, DS_PZ = 6, DS_NOISE = 7, DS_NSLOT = 8,
                 DS_PRIOR = DS_ALLH /* BVRNN.forward has no all_h output: the slot carries the prior probabilities */,
                 DS_PARTD = DS_PX, DS_PARTG = DS_CODES /* decode has neither: pre-computed phi_z halves of dec.0 / of the GRU input */,
-                DS_KEEP = DS_PROB /* decode with the folded hop: ELU(dec.4) of all frames, (B,T,H) */ };
+                DS_KEEP = DS_PROB /* decode with the folded hop: ELU(dec.4) of all frames, (B,T,H) */,
+                DS_KEEP_ENC = DS_PZ /* ... and encode's, when the fused forward wants the decoder's output (encode has no phi_z tensor) */ };
 struct CallDesc {
     float *p[DS_NSLOT];              // base pointers of the (B, T, dim) tensors of this call (may be null)
     long long T;                     // frames per utterance

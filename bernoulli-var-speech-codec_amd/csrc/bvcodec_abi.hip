@@ -726,12 +726,12 @@ std::vector<StepNode> build_step(const bvc_model *m, const Workspace &w, int B, 
         // one launch less per frame: u = ELU(dec.4) (decode: also kept for all frames - dec.6(u), the decoder's output, is one batched
         // GEMM behind the recurrence), then phi_x.0(norm(dec.6(u))) as the one folded layer
         GemmParams p = lin_params(m->dec[2], S(d2, H), B, S(d3, H));
-        if (kind != STEP_ENCODE) p.y2 = dp_frame(DS_KEEP, H);
+        p.y2 = dp_frame(kind != STEP_ENCODE ? DS_KEEP : DS_KEEP_ENC, H);       // (encode: a null slot unless the fused forward wants mel^)
         K(BR_MAIN, p, EPI_ELU);
         K(BR_MAIN, lin_params(m->px0_dec3, S(d3, H), B, S(g1, H)), EPI_ELU);
     } else {
         K(BR_MAIN, lin_params(m->dec[2], S(d2, H), B, S(d3, H)), EPI_ELU);
-        GemmParams p = lin_params(m->dec[3], S(d3, H), B, kind != STEP_ENCODE ? dp_frame(DS_MEL, X) : dp_null());
+        GemmParams p = lin_params(m->dec[3], S(d3, H), B, dp_frame(DS_MEL, X));      // (encode: a null slot unless the fused forward wants mel^)
         p.y2 = S(dn, X); p.mean = m->mean_mel; p.stdv = m->std_mel;
         K(BR_MAIN, p, EPI_MEL);
         K(BR_MAIN, lin_params(m->phi_x[0], S(dn, X), B, S(g1, H)), EPI_ELU);
@@ -1169,7 +1169,8 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, int chains, co
     a.part0 = w.part_dec0;
     a.part_gru = encode ? nullptr : w.part_gru;
     a.codes = d_codes; a.prob = d_prob; a.bits = d_bits; a.all_h = d_all_h; a.mel = d_mel;
-    a.keep = w.pxB;                             // folded decode: ELU(dec.4) of all frames (pxB is idle once the batched phi_z layers are through)
+    a.keep = (encode && !d_mel) ? nullptr : w.pxB;   // folded hop: ELU(dec.4) of all frames (pxB is idle once the batched phi_x / phi_z layers are through);
+                                                     // encode keeps it only when the caller wants the decoder's output too (bvc_forward)
     a.mean = m->mean_mel; a.stdv = m->std_mel;
     a.var_bit = m->cfg.var_bit;
     a.status = m->d_status;
@@ -1307,9 +1308,11 @@ int decode_epilogue(const bvc_model *m, const float *keep, int B, int64_t T, flo
     return launch_gemm_batched(keep, H, m->dec[3].w, H, m->dec[3].b, BT, X, H, 0, d_mel, X, s);
 }
 
+// d_melhat (optional): the decoder's output dec(phi_z(z_t), h_t) of every frame (B,T,num_mels) - what BVRNN.decode(codes) would compute over again
+// from the same trajectory (bvrnn.py:202 vs :224-225; the fused forward, bvc_forward)
 int run_encode_body(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_mel, const float *d_bits,
                     const float *d_h0, int B, int64_t T, float *d_codes, float *d_all_h, float *d_hT, float *d_prob,
-                    hipStream_t s) {
+                    float *d_melhat, hipStream_t s) {
     const int H = m->cfg.h_dim, X = m->cfg.num_mels;
     const long long BT = (long long)B * T;
     int rc;
@@ -1318,7 +1321,7 @@ int run_encode_body(const bvc_model *m, const Workspace &w, void *ws_base, const
     if ((rc = launch_normalize_rows(d_mel, m->mean_mel, m->std_mel, BT, X, w.yn, s))) return rc;
     const int chains = flow_chains(m, B, s);
     if ((rc = encode_prologue(m, w, B, T, s))) return rc;
-    if (chains) return run_flow(m, w, true, chains, d_h0, B, T, d_bits, d_codes, d_prob, d_all_h, nullptr, d_hT, s);
+    if (chains) return run_flow(m, w, true, chains, d_h0, B, T, d_bits, d_codes, d_prob, d_all_h, d_melhat, d_hT, s);
     if ((rc = init_state(w, d_h0, B, H, s))) return rc;
     if (d_all_h && (rc = launch_repack_rows(w.hbuf, d_all_h, (long long)T * H, B, H, 1, s))) return rc;
     CallDesc d;
@@ -1327,16 +1330,21 @@ int run_encode_body(const bvc_model *m, const Workspace &w, void *ws_base, const
     d.p[DS_PROB] = d_prob; d.p[DS_ALLH] = d_all_h;
     d.T = T;
     const int kind_e = STEP_ENCODE | step_fold(m, true, T);
+    if (d_melhat) {                                   // folded: keep ELU(dec.4) of every frame, dec.6 behind the recurrence; else dec.6's own output
+        if (kind_e & STEP_FOLD) d.p[DS_KEEP_ENC] = w.pxB;
+        else d.p[DS_MEL] = d_melhat;
+    }
     if ((rc = begin_call(m, w, d, count_kernels(build_step(m, w, B, kind_e)), s))) return rc;
     if ((rc = run_recurrence(m, w, ws_base, B, T, kind_e, s))) return rc;
     if (d_hT && (rc = read_state(w, B, H, T, d_hT, s))) return rc;
+    if (d_melhat && (kind_e & STEP_FOLD) && (rc = decode_epilogue(m, w.pxB, B, T, d_melhat, s))) return rc;
     return BVC_OK;
 }
 
 int run_encode(const bvc_model *m, const Workspace &w, void *ws_base, const float *d_mel, const float *d_bits,
                const float *d_h0, int B, int64_t T, float *d_codes, float *d_all_h, float *d_hT, float *d_prob,
-               hipStream_t s) {
-    const int rc = run_encode_body(m, w, ws_base, d_mel, d_bits, d_h0, B, T, d_codes, d_all_h, d_hT, d_prob, s);
+               hipStream_t s, float *d_melhat = nullptr) {
+    const int rc = run_encode_body(m, w, ws_base, d_mel, d_bits, d_h0, B, T, d_codes, d_all_h, d_hT, d_prob, d_melhat, s);
     const int rc2 = mark_call_end(s);
     return rc ? rc : rc2;
 }
@@ -1887,6 +1895,27 @@ int bvc_encode(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, flo
     if ((rc = launch_stft_logmel(m->fe, d_wav, B, L, T, m->cfg.pad_left, scale, w.mel, s))) return rc;
     if ((rc = launch_fill(w.bits, bits_per_frame, (long long)B * T, s))) return rc;
     return run_encode(m, w, d_ws, w.mel, w.bits, nullptr, B, T, d_codes, nullptr, nullptr, nullptr, s);
+}
+
+int bvc_forward(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, float scale, float bits_per_frame, int64_t length,
+                float out_scale_div, float *d_codes, float *d_wav_out, void *d_ws, size_t ws_bytes, void *stream) {
+    if (int st_ = sticky_status(m)) return st_;
+    if (!m) { set_error("null model"); return BVC_EINVAL; }
+    const int64_t T = bvc_num_frames(m, L);
+    if (T <= 0) { set_error("input too short for reflect padding (L=%lld)", (long long)L); return BVC_EINVAL; }
+    Workspace w;
+    int rc = check_ws(m, B, T, d_ws, ws_bytes, &w);
+    if (rc) return rc;
+    if (!d_wav || !d_wav_out || length <= 0) { set_error("null argument or non-positive length"); return BVC_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = launch_stft_logmel(m->fe, d_wav, B, L, T, m->cfg.pad_left, scale, w.mel, s))) return rc;
+    if ((rc = launch_fill(w.bits, bits_per_frame, (long long)B * T, s))) return rc;
+    // the encoder's recurrence runs the decoder of every frame anyway (bvrnn.py:198-204): its outputs ARE what BVRNN.decode(codes) would
+    // compute over again from the same states.  w.mel has been consumed (normalised into another buffer) before the first of them is
+    // written; codes nobody asked for go to a workspace tensor that encode does not use.
+    float *codes = d_codes ? d_codes : w.part_gru;
+    if ((rc = run_encode(m, w, d_ws, w.mel, w.bits, nullptr, B, T, codes, nullptr, nullptr, nullptr, s, w.mel))) return rc;
+    return run_vocoder(m, w, w.mel, B, T, length, out_scale_div, d_wav_out, -1, nullptr, nullptr, nullptr, s);
 }
 
 int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, int64_t length, float out_scale_div,

@@ -504,7 +504,7 @@ __device__ __forceinline__ void flow_publish(const FlowCtx &c, int hopid, const 
     // The slot that will receive h(t+1) still holds h(t-1).  This layer's input was produced by workgroups that had all
     // consumed h(t), i.e. had all finished frame t-1: nobody reads h(t-1) any more (same tile shape as this layer's).
     if (REARM_H) __builtin_amdgcn_raw_buffer_store_b128(poison4, g.rs, (unsigned)(FB_H * 2 + (c.par ^ 1u)) * c.sb + ytile, 0, AUX_SC1);
-    if (EPI == FE_ELU_KEEP && c.rowok) *reinterpret_cast<f32x4 *>(a.keep + c.fr * (ntiles * 16) + n0) = o;     // (behind the hand-off stores)
+    if (EPI == FE_ELU_KEEP && c.rowok && a.keep) *reinterpret_cast<f32x4 *>(a.keep + c.fr * (ntiles * 16) + n0) = o;     // (behind the hand-off stores; encode keeps u only for the fused forward)
     if (EPI == FE_CODE && c.rowok) {                    // the call's outputs: behind the hand-off stores as well (-0.06 ms per step)
         *reinterpret_cast<f32x4 *>(a.codes + c.fr * (ntiles * 16) + n0) = o;
         if (a.prob) *reinterpret_cast<f32x4 *>(a.prob + c.fr * (ntiles * 16) + n0) = pr;
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                 }
                 flow_layer<PERH, FE_ELU, false, false, true, !P9, PERH, false, G1, NW>(c, 8, L(a.dec1), FB_D1, L(a.dec1), 0, hb, hb, FB_D2, w8, L(a.dec2), wa, gq, zero4, f_iz, &c.fgi[1]);
                 if (folded) {
-                    flow_layer<PERH, FE_ELU, false, false, true, true, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, w9, L(a.pxc), wb, gq, zero4, f_iz, &c.fgi[2]);
+                    flow_layer<PERH, FE_ELU_KEEP, false, false, true, true, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, w9, L(a.pxc), wb, gq, zero4, f_iz, &c.fgi[2]);
                     flow_layer<PERH, FE_ELU, false, false, true, !P12, PERH, false, -2, NW>(c, 11, L(a.pxc), FB_D3, L(a.pxc), 0, hb, hb, FB_G1, wb, L(a.px1), wa, gq);
                 } else {
                     flow_layer<PERH, FE_ELU, false, false, true, false, PERH, false, G2, NW>(c, 9, L(a.dec2), FB_D2, L(a.dec2), 0, hb, hb, FB_D3, w9, L(a.dec2), wb, gq, zero4, f_iz, &c.fgi[2]);
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
                 }
                 flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 8, L(a.dec1), FB_D1, hb, hb, FB_D2, wb, L(a.dec2), wa, mt0, nch, T);
                 if (folded) {
-                    flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.pxc), wb, mt0, nch, T);
+                    flow_layer_chains<PERH, FE_ELU_KEEP, false, true, true, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.pxc), wb, mt0, nch, T);
                     flow_layer_chains<PERH, FE_ELU, false, true, true, PERH, false, NW>(c, 11, L(a.pxc), FB_D3, hb, hb, FB_G1, wb, L(a.px1), wa, mt0, nch, T);
                 } else {
                     flow_layer_chains<PERH, FE_ELU, false, true, false, PERH, false, NW>(c, 9, L(a.dec2), FB_D2, hb, hb, FB_D3, wa, L(a.dec2), wb, mt0, nch, T);

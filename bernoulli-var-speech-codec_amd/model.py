@@ -420,6 +420,33 @@ class BVRNNCodecModel(_OnDevice):
         codes = self.encode(x, bitrate)
         return self.decode(codes, length)
 
+    @torch.no_grad()
+    def forward_fused(self, x, bitrate, return_codes=False):
+        """``forward(x, bitrate)`` with ONE recurrence instead of two (``bvc_forward``): the encoder's frame loop already runs the
+        decoder on every frame (bvrnn.py:198-204) from the states ``decode`` would visit again, so its outputs go to the vocoder
+        directly.  Same codes as ``encode``; the waveform agrees with ``forward`` to rounding (the halves of dec.0 and of the GRU's
+        input gates are summed in another order).  ``forward`` itself stays the reference's decode(encode(x))."""
+        eng = self.engine(x)
+        out_dev = x.device
+        x = _prep(x, eng.device)
+        if x.dim() != 2:
+            raise RuntimeError("expected a (batch, length) waveform")
+        B, L = x.shape
+        T = eng.num_frames(L)
+        if T <= 0:
+            raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension "
+                               f"(length {L} is too short for the reflect padding of the STFT front-end)")
+        n = _trimmed(eng.vocoder_length(T), L)
+        wav = torch.empty(B, n, device=eng.device)
+        codes = torch.empty(B, T, self.conf["z_dim"], device=eng.device) if return_codes else None
+        ws, nws = eng.workspace(B, T)
+        with torch.cuda.device(eng.device):
+            _abi.check(eng.lib.bvc_forward(eng.handle, _abi.ptr(x), B, L, float(SCALING), self.bits_per_frame(bitrate), n, float(SCALING),
+                                           _abi.ptr(codes), _abi.ptr(wav), ws, nws, eng.stream()))
+        if return_codes:
+            return codes.to(out_dev), eng.deliver(wav, out_dev)
+        return eng.deliver(wav, out_dev)
+
     # ---- wire format (not in the reference, which has no bit stream: SURVEY.md 8f rank 2)
     def active_bits(self, bitrate):
         z = self.conf["z_dim"]

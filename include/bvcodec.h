@@ -45,7 +45,7 @@ extern "C" {
 #endif
 
 #define BVC_ABI_VERSION 3   /* 2: + bvc_model_get_option, bvc_flow_fence, bvc_kprobe_read_span; recurrence option takes 2 (auto); status word reported by every compute entry
-                             * 3: + bvc_model_poll_status */
+                             * 3: + bvc_model_poll_status, bvc_forward */
 
 enum {
     BVC_OK = 0,
@@ -245,6 +245,15 @@ int bvc_encode(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, flo
 /* BVRNNCodecModel.decode (bvrnn_codec_model.py:64-71): zero state, BVRNN.decode, vocoder, /scale. */
 int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, int64_t length,
                float out_scale_div, float *d_wav, void *d_ws, size_t ws_bytes, void *stream);
+
+/* BVRNNCodecModel.forward (bvrnn_codec_model.py:73-76: decode(encode(x, bitrate), x.shape[1])) WITHOUT the second recurrence.  The
+ * encoder's frame loop already runs the decoder on every frame (bvrnn.py:198-204) from exactly the states BVRNN.decode would visit
+ * again from the same codes (bvrnn.py:222-227), so its outputs are handed to the vocoder directly: one recurrence launch instead of two,
+ * no all-frame phi_z GEMMs.  Not a replacement for bvc_encode + bvc_decode (which stay the reference's two operators and the path the
+ * benchmark's headline times): the two differ in the ORDER in which dec.0 and the GRU's input gates sum their halves, i.e. by rounding
+ * (tests: waveform within 1e-5 RMS of bvc_decode(bvc_encode(x)), codes identical).  d_codes (B, T, z_dim) optional. */
+int bvc_forward(const bvc_model *m, const float *d_wav, int32_t B, int64_t L, float scale, float bits_per_frame, int64_t length,
+                float out_scale_div, float *d_codes, float *d_wav_out, void *d_ws, size_t ws_bytes, void *stream);
 
 /* Pre-processing of the reference's example.py:15-17.
  * bvc_resample_poly: y = upfirdn(h, x, up, down)[n_pre_remove : n_pre_remove + n_out] with zero padding, i.e.

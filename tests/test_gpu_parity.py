@@ -614,3 +614,43 @@ def test_execution_variants_agree(env):
     mel_c, h_c = inrec.bvrnn.decode(codes, torch.zeros(1, 5, 1024, device=DEV))
     assert (mel_a - mel_c).abs().max().item() < 1e-5
     assert torch.equal(inrec.encode(x, 3000), codes)
+
+
+@pytest.mark.parametrize("B", [5, 64, 130])
+def test_fused_forward_equals_encode_plus_decode_to_rounding(env, B):
+    """model.forward_fused (bvc_forward): the decoder outputs of the ENCODER's frame loop (bvrnn.py:198-204) go to the vocoder, no second
+    recurrence.  Codes are encode()'s bit for bit; the waveform agrees with forward() = decode(encode(x)) (bvrnn_codec_model.py:73-76) to
+    rounding (the halves of dec.0 and of the GRU's input gates are summed in another order) and with the oracle's forward within the
+    north-star bar; the same bits on the persistent kernel (one group per workgroup / interleaved chains) and on the layer schedule, with and
+    without the folded hop."""
+    from bvcodec import synth
+    from oracle import codec as ocodec
+    model, conf, vr, ge = env
+    eng = model.engine()
+    L = 256 * 30 + 100
+    x = synth.synthetic_speech(B, L, seed=40 + B, kind="speech").to(DEV)
+    codes = model.encode(x, 3000)
+    ref = model.forward(x, 3000)
+    out = {}
+    try:
+        for sched in ("persistent", "layers"):
+            model.set_recurrence(sched)
+            for fold in (1, 0):
+                eng.set_option("encode_fold", fold)
+                c, w = model.forward_fused(x, 3000, return_codes=True)
+                assert torch.equal(c, codes), (sched, fold)
+                out[(sched, fold)] = w
+        torch.cuda.synchronize()
+        model.check_status()
+    finally:
+        eng.set_option("encode_fold", 1)
+        model.set_recurrence("auto")
+    for fold in (1, 0):
+        assert torch.equal(out[("persistent", fold)], out[("layers", fold)]), fold
+    for k, w in out.items():
+        assert w.shape == ref.shape
+        assert float((w - ref).pow(2).mean().sqrt()) < 1e-5, k
+    oc = ocodec.OracleCodec(conf, vr, ge)
+    pick = [0, B - 1]
+    ow = oc.forward(x[pick].cpu(), 3000)
+    assert float((out[("persistent", 1)][pick].cpu() - ow).pow(2).mean().sqrt()) < 1e-4
