@@ -124,6 +124,21 @@ def rocprof_avg_us(kernel_substr):
     return round(tot / n, 3) if n else None
 
 
+def pmc_l2_to_cu_bytes(kernel_substr):
+    """Bytes that came out of the L2s into the compute units per launch (TCP_TCC_READ_REQ_sum x 128 B) from the same committed PMC summary,
+    launch-weighted; None if absent.  This - not HBM and not the matrix pipe - is what the recurrence kernel leans on."""
+    if not os.path.exists(PMC_SUMMARY):
+        return None
+    import csv
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(PMC_SUMMARY)):
+        if kernel_substr in r["kernel"] and r.get("TCP_TCC_READ_REQ_sum_avg"):
+            k = int(r["launches"])
+            tot += k * float(r["TCP_TCC_READ_REQ_sum_avg"]) * 128.0
+            n += k
+    return round(tot / n) if n else None
+
+
 def pmc_traffic_bytes(kernel_substr):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc pass (FETCH_SIZE x2 per the gfx950 correction of
     MI355X_MICROARCH.md + WRITE_SIZE), launch-weighted.  PMC collection serialises every dispatch, so it is a separate pass
@@ -641,16 +656,20 @@ def main():
                            "traffic": pmc_traffic_bytes("bvrnn_flow_kernel") if dom == 1 else None,
                            "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate pass: "
                                            f"profiles/{os.path.basename(PMC_SUMMARY)}); algorithmic: the weights once per frame "
-                                           "(85 / 60 MB encode / decode, served by the 256 MB Infinity Cache) + 0.25 MB per audio-second of I/O",
+                                           "that are not resident on the chip (80 / 53 MB encode / decode, served by the 256 MB Infinity Cache) + 0.25 MB per audio-second of I/O",
                            "kernel": r["kernel"], "mean_launch_us": r["mean_us"],
                            "launches_per_step": r["launches_per_step"], "gflop_per_launch": round(fl / launches / 1e9, 1),
                            "timer": r["timer"],
                            "rocprof_avg_us": rp,
                            "frac_rocprof": round(fl / launches / (rp * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if rp else None,
                            "rocprof_source": f"profiles/{os.path.basename(ROCPROF_SUMMARY)} (rocprofv3 --kernel-trace --stats of this command)",
-                           "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32).  One launch runs every layer of every frame; it is "
-                                   "bound by the hand-offs between dependent layers (two write-through / L1-bypassing round trips "
-                                   "of ~0.85 us per layer) and by the per-CU operand stream, not by the matrix pipe (DESIGN.md 4)"}
+                           "note": "fp32-in/fp32-acc MFMA (v_mfma_f32_16x16x4_f32).  One launch runs every layer of every frame; it leans on "
+                                   "the hand-offs between dependent layers (a flag poll and an operand fetch through the fabric per layer) and on "
+                                   "the L2 -> CU fill path (l2_to_cu), not on the matrix pipe (busy 39 % of the time) or on HBM (DESIGN.md 4)"}
+        l2b = pmc_l2_to_cu_bytes("bvrnn_flow_kernel") if dom == 1 else None
+        if l2b:
+            out["roofline"]["l2_to_cu"] = {"bytes_per_launch": l2b, "tb_per_s": round(l2b / (r["mean_us"] * 1e-6) / 1e12, 2),
+                                           "source": f"TCP_TCC_READ_REQ_sum x 128 B, profiles/{os.path.basename(PMC_SUMMARY)} (separate --pmc pass), over this run's launch time"}
         # SURVEY.md 8(d) also asks for the whole path against the fp32 peak: algorithmic FLOPs of a step (all families)
         # over the measured step time of the timed region
         step_flops = sum(f for f, _ in fam.values())
