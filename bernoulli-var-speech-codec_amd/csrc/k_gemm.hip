@@ -501,6 +501,20 @@ __global__ __launch_bounds__(256, 2) void gemm_batched_kernel(const float *__res
         xv[i] = *reinterpret_cast<const f32x4 *>(xp[i]);
         wv[i] = *reinterpret_cast<const f32x4 *>(wp[i]);
     }
+    // one k-block; START: the block opens a chunk - its first MFMA per tile starts from zero (no accumulator to clear)
+    auto block = [&](auto start_c) {
+        constexpr bool START = decltype(start_c)::value;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 c = (START && e == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][j];
+                    acc[i][j] = ROWVEC ? mfma16(wv[j][e], xv[i][e], c) : mfma16(xv[i][e], wv[j][e], c);
+                }
+    };
+    bool cstart = true;
 #pragma unroll 1
     for (int kb = 0; kb < nblk; ++kb) {
         const long long nxt = (long long)(kb + 1 < nblk ? kb + 1 : nblk - 1) * 16;
@@ -510,24 +524,17 @@ __global__ __launch_bounds__(256, 2) void gemm_batched_kernel(const float *__res
             wn[i] = *reinterpret_cast<const f32x4 *>(wp[i] + nxt);
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = ROWVEC ? mfma16(wv[j][e], xv[i][e], acc[i][j]) : mfma16(xv[i][e], wv[j][e], acc[i][j]);
+        if (cstart) block(std::true_type());
+        else        block(std::false_type());
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { xv[i] = xn[i]; wv[i] = wn[i]; }
-        if (kb + 1 == cend) {                              // (uniform) block kb ends chunk `chunk`: add it to the sum, start the next one from zero
+        cstart = kb + 1 == cend;
+        if (cstart) {                                      // (uniform) block kb ends chunk `chunk`: add it to the sum
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    tot[i][j] = first_chunk ? acc[i][j] : tot[i][j] + acc[i][j];
-                    acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
+                for (int j = 0; j < 4; ++j) tot[i][j] = first_chunk ? acc[i][j] : tot[i][j] + acc[i][j];
             first_chunk = false;
             do { ++chunk; cend = (nblk * (chunk + 1)) >> 3; } while (chunk < 7 && cend == kb + 1);     // (empty chunks: K < 128)
         }
