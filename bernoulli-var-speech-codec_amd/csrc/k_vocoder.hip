@@ -492,23 +492,29 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
             t2[(row + 1) * S + col] = row + 1 >= zrow ? s2[1] : 0.0f;
         }
     } else {
+        // (all tiles but the first of a signal lie wholly inside it: no row to zero - two selects per pair less; the test is uniform)
+        auto s2_tile = [&](auto edge_c) {
+            constexpr bool EDGE = decltype(edge_c)::value;
 #pragma unroll
-        for (int n = 0; n < NTL; ++n) {
-            const int col = (nt0 + n) * 16 + r;
-            if (col < C) {
-                const float bias = a.b1[col], aa = a.a2[col], bb = a.ib2[col];
+            for (int n = 0; n < NTL; ++n) {
+                const int col = (nt0 + n) * 16 + r;
+                if (col < C) {
+                    const float bias = a.b1[col], aa = a.a2[col], bb = a.ib2[col];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; e += 2) {
-                        const int row = mbase + i * 16 + g * 4 + e;
-                        const f32x2 u2 = (f32x2){acc[i][n][e] + bias, acc[i][n][e + 1] + bias};
-                        const f32x2 s2 = snakebeta2(u2, splat2(aa), splat2(bb));
-                        t2[row * S + col] = row >= zrow ? s2[0] : 0.0f;
-                        t2[(row + 1) * S + col] = row + 1 >= zrow ? s2[1] : 0.0f;
-                    }
+                        for (int e = 0; e < 4; e += 2) {
+                            const int row = mbase + i * 16 + g * 4 + e;
+                            const f32x2 u2 = (f32x2){acc[i][n][e] + bias, acc[i][n][e + 1] + bias};
+                            const f32x2 s2 = snakebeta2(u2, splat2(aa), splat2(bb));
+                            t2[row * S + col] = (!EDGE || row >= zrow) ? s2[0] : 0.0f;
+                            t2[(row + 1) * S + col] = (!EDGE || row + 1 >= zrow) ? s2[1] : 0.0f;
+                        }
+                }
             }
-        }
+        };
+        if (zrow > 0) s2_tile(std::true_type());
+        else          s2_tile(std::false_type());
     }
     __syncthreads();
     PHASE(2);
@@ -716,20 +722,25 @@ __global__ __launch_bounds__(256, OCC) void amp_pair8_kernel(AmpArgs a) {
         {
             const long long zr64 = -(tbase + a.t_origin);  // local rows before zrow lie before the start of the signal: zero
             const int zrow = zr64 <= 0 ? 0 : (zr64 > TR ? TR : (int)zr64);      // (the reference pads AFTER the activation)
+            auto s2_tile = [&](auto edge_c) {                  // (only a signal's first tile has rows to zero: the test is uniform)
+                constexpr bool EDGE = decltype(edge_c)::value;
 #pragma unroll
-            for (int i = 0; i < MT2; ++i) {
-                const int m = mbase + i * 16 + r;          // this lane's pair; its row of column block p
-                const int row = pair_row<D>(m) + p * D;
-                const f32x4 u4 = acc[i] + bias1;
-                const f32x2 s01 = snakebeta2((f32x2){u4[0], u4[1]}, (f32x2){aa2[0], aa2[1]}, (f32x2){bb2[0], bb2[1]});
-                const f32x2 s23 = snakebeta2((f32x2){u4[2], u4[3]}, (f32x2){aa2[2], aa2[3]}, (f32x2){bb2[2], bb2[3]});
-                const bool keep = row >= zrow;
-                if (NPE == NP || m < NPE) {
-                    float2 *dst = reinterpret_cast<float2 *>(lds + row_pos<1>(row, H2) * S + co0);
-                    dst[0] = keep ? make_float2(s01[0], s01[1]) : make_float2(0.f, 0.f);
-                    dst[1] = keep ? make_float2(s23[0], s23[1]) : make_float2(0.f, 0.f);
+                for (int i = 0; i < MT2; ++i) {
+                    const int m = mbase + i * 16 + r;      // this lane's pair; its row of column block p
+                    const int row = pair_row<D>(m) + p * D;
+                    const f32x4 u4 = acc[i] + bias1;
+                    const f32x2 s01 = snakebeta2((f32x2){u4[0], u4[1]}, (f32x2){aa2[0], aa2[1]}, (f32x2){bb2[0], bb2[1]});
+                    const f32x2 s23 = snakebeta2((f32x2){u4[2], u4[3]}, (f32x2){aa2[2], aa2[3]}, (f32x2){bb2[2], bb2[3]});
+                    const bool keep = !EDGE || row >= zrow;
+                    if (NPE == NP || m < NPE) {
+                        float2 *dst = reinterpret_cast<float2 *>(lds + row_pos<1>(row, H2) * S + co0);
+                        dst[0] = keep ? make_float2(s01[0], s01[1]) : make_float2(0.f, 0.f);
+                        dst[1] = keep ? make_float2(s23[0], s23[1]) : make_float2(0.f, 0.f);
+                    }
                 }
-            }
+            };
+            if (zrow > 0) s2_tile(std::true_type());
+            else          s2_tile(std::false_type());
             // rows conv1 did not produce ([TR1, TR + KS]): read only by discarded outputs, but keep them defined
             for (int idx = tid; idx < (TR + KS + 1 - G::TR1) * C; idx += 256) {
                 const int row = G::TR1 + idx / C;
@@ -958,15 +969,20 @@ __global__ __launch_bounds__(256, OCC) void amp_pair16_kernel(AmpArgs a) {
         {
             const long long zr64 = -(tbase + a.t_origin);  // local rows before zrow lie before the start of the signal
             const int zrow = zr64 <= 0 ? 0 : (zr64 > TR ? TR : (int)zr64);      // (the reference pads AFTER the activation)
+            auto s2_tile = [&](auto edge_c) {                  // (only a signal's first tile has rows to zero: the test is uniform)
+                constexpr bool EDGE = decltype(edge_c)::value;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int row = mbase + i * 16 + r;
-                const f32x4 u4 = acc[i] + bias1;
-                const f32x2 s01 = snakebeta2((f32x2){u4[0], u4[1]}, (f32x2){aa2[0], aa2[1]}, (f32x2){bb2[0], bb2[1]});
-                const f32x2 s23 = snakebeta2((f32x2){u4[2], u4[3]}, (f32x2){aa2[2], aa2[3]}, (f32x2){bb2[2], bb2[3]});
-                const bool keep = row >= zrow;
-                *reinterpret_cast<f32x4 *>(t2 + row * S + g * 4) = keep ? (f32x4){s01[0], s01[1], s23[0], s23[1]} : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
+                for (int i = 0; i < MT; ++i) {
+                    const int row = mbase + i * 16 + r;
+                    const f32x4 u4 = acc[i] + bias1;
+                    const f32x2 s01 = snakebeta2((f32x2){u4[0], u4[1]}, (f32x2){aa2[0], aa2[1]}, (f32x2){bb2[0], bb2[1]});
+                    const f32x2 s23 = snakebeta2((f32x2){u4[2], u4[3]}, (f32x2){aa2[2], aa2[3]}, (f32x2){bb2[2], bb2[3]});
+                    const bool keep = !EDGE || row >= zrow;
+                    *reinterpret_cast<f32x4 *>(t2 + row * S + g * 4) = keep ? (f32x4){s01[0], s01[1], s23[0], s23[1]} : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            };
+            if (zrow > 0) s2_tile(std::true_type());
+            else          s2_tile(std::false_type());
         }
         __syncthreads();
 
