@@ -90,7 +90,7 @@ namespace {
 //   BVC_GRU_FENCE         1 (default): scheduling fences around the rounds of the GRU layer's weight stream (see flow_gru)
 //   BVC_GRU_DEPTH         register sets the stream runs through (default 3; 2: the request for round i + 1 in front of round i's products; up to all four rounds)
 //   BVC_FLOW_PARKV        2 (default; 0 off, 1 two layers): (filler form) the weights of two wide layers (three in decode) - this wave's 8 blocks each - stay in registers for the whole launch
-//                         (the filler kernels use 165 of the 256 VGPRs a wave may have): 128 KiB per compute unit and frame less to pull from
+//                         (the filler kernels use 165 of the 256 VGPRs a wave may have): 128 KiB (decode 192) per compute unit and frame less to pull from
 //                         the L2, whose fill path into the compute units is what the kernel is bound by
 #ifndef BVC_FLOW_PARKV
 #define BVC_FLOW_PARKV 2
@@ -1064,7 +1064,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? BVC_FLOW_WAVES_PER_SIMD : 1) voi
     c.a = ap;
     // LDS: [2][NW][256] layer partials | [NW][6][256] GRU partials | MULTI: [2][4][NW][256] partials of a group of chains.  Filler kernels: the waves' operand stashes
     // (NW x 8 KiB) lie over the GRU partials - the stashes are dead from the last quantum (layer 9) to the next frame's first layer,
-    // whose operand, h(t+1), exists only after wave 0 has read the partials -, then the parked GRU weights (NW x 6 KiB), then the flag.
+    // whose operand, h(t+1), exists only after wave 0 has read the partials -, then the parked weights (NW x 8 KiB: the first layer's, BVC_FLOW_PARKL;
+    // or a quarter of the GRU layer's, BVC_GRU_FAST), then the flag.
     c.red_lin = lds;
     c.red_gru = lds + 2 * NW * 256;
     c.red_chain = lds + 2 * NW * 256 + NW * 6 * 256;      // (MULTI only: FLOW_LDS_MULTI)
