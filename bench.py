@@ -25,7 +25,7 @@ one stream.  Rank 0 prints ONE JSON line: metric/value (audio-seconds coded per 
   target_workload / encode_only / streaming - BASELINE configs[3]'s per-GPU shard (64 x 10 s, the north-star target's
                   utterance length; bitrates 1.5 / 3 / 6 kbit/s; with --gpus N > 1 EVERY rank runs its shard, the per-step
                   all-gather included, max over ranks), configs[2] (encode only) and configs[4] (256 streams x 20 ms hops,
-                  one hipGraph-replayed library call per hop: p50 / p99), each timed after the headline with its own parity
+                  one library call per hop: p50 / p99), each timed after the headline with its own parity
                   spot check (the last two at N = 1 only)
   cpu_baseline  - the CPU oracle (oracle/, PyTorch-CPU port of the reference op sequence) timed on the host
                   cores on a bounded sample of the same workload (rank 0, N=1 only): the benchmark's batch of 64, one
@@ -423,7 +423,7 @@ def leg_encode_only(conf, model, device, x, bitrate, ref_codes, steps=5):
 
 def leg_streaming(conf, model, device, bitrate, with_parity, streams=256, hop=441, ticks=300):
     """BASELINE configs[4]: `streams` concurrent streams, 20 ms hops, one library call per hop (front-end -> encode -> decode ->
-    incremental vocoder), replayed from a hipGraph once warm; host-observed latency per hop (synchronised)."""
+    incremental vocoder; the recurrences on the persistent kernel); host-observed latency per hop (synchronised)."""
     from bvcodec.streaming import StreamingCodec
     x = synth.synthetic_speech(streams, hop * ticks, seed=3, kind="noise").to(device)
     sc = StreamingCodec(model, streams, bitrate, hop=hop)
@@ -443,7 +443,7 @@ def leg_streaming(conf, model, device, bitrate, with_parity, streams=256, hop=44
     import numpy as np
     l = np.array(lat[50:]) * 1e3
     out = {"workload": f"BASELINE configs[4]: {streams} streams x {hop}-sample (20 ms) hops @ {bitrate:g} bit/s, encode + decode per hop, "
-                       "bvc_stream_codec_tick replayed from a hipGraph",
+                       "one bvc_stream_codec_tick per hop (persistent recurrence kernel; BVC_STREAM_FLOW=0: a replayed hipGraph of launch-per-layer kernels)",
            "p50_ms": round(float(np.percentile(l, 50)), 3), "p99_ms": round(float(np.percentile(l, 99)), 3), "mean_ms": round(float(l.mean()), 3),
            "hop_budget_ms": round(1e3 * hop / FS, 2), "ticks": ticks, "ticks_timed": int(l.size), "frames_per_hop": round(frames / ticks, 3),
            "value": round(streams * (hop / FS) / (float(l.mean()) * 1e-3), 1), "unit": "audio-seconds/s (all streams, at the mean hop latency)"}

@@ -31,7 +31,8 @@ struct ProbeState {
 };
 static ProbeState g_probe;
 static thread_local bool g_capturing = false;   // no event probes while THIS thread captures a stream (captures are thread-local)
-static thread_local bool g_stream_tick = false;   // inside bvc_stream_codec_tick: launch-per-layer schedule, launched eagerly (the tick itself is the graph)
+static thread_local bool g_stream_tick = false;   // inside bvc_stream_codec_tick: a launch-per-layer recurrence is launched eagerly (the tick itself is the graph)
+static thread_local bool g_tick_flow = false;     // ... of a tick that is NOT a graph: its recurrences may take the persistent kernel
 
 // in-kernel timestamp probes for the graph-replayed recurrent kernels (wall_clock64, 100 MHz)
 struct KProbe {
@@ -1020,7 +1021,7 @@ inline int flow_grid_tiles(const bvc_model *m) {          // feature tiles cover
     return ((H > X ? (H > Z ? H : Z) : (X > Z ? X : Z)) / 16 + 7) / 8 * 8;
 }
 inline int flow_chains_static(const bvc_model *m, int B) {      // 0: not usable; else utterance groups per workgroup
-    if (m->recurrence == RS_LAYERS || m->side_branch || !m->flow_resident || g_stream_tick || m->flow_perh <= 0) return 0;
+    if (m->recurrence == RS_LAYERS || m->side_branch || !m->flow_resident || (g_stream_tick && !g_tick_flow) || m->flow_perh <= 0) return 0;
     const int ntg = flow_grid_tiles(m);
     const int mt = (B + 15) / 16;
     const int slots = m->cu_count / ntg;                   // workgroups per feature tile that fit on the device
@@ -1049,7 +1050,7 @@ constexpr int AUTO_HOLD = 2;
 // Which schedule does THIS call take?  0: launch per layer; else utterance groups per workgroup of the persistent kernel.
 // Called once per recurrence-bearing call (run_encode / run_decode); mark_call_end() follows at its end.
 int flow_chains(const bvc_model *m, int B, hipStream_t s) {
-    if (m->census_due && !g_stream_tick) {               // a time-out was reported: is a full grid still co-resident?  (synchronises: error path only)
+    if (m->census_due && (!g_stream_tick || g_tick_flow)) {               // a time-out was reported: is a full grid still co-resident?  (synchronises: error path only)
         hipStreamCaptureStatus cs0 = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cs0) == hipSuccess && cs0 == hipStreamCaptureStatusNone) {
             m->census_due = false;
@@ -1720,6 +1721,7 @@ struct bvc_stream_codec {
     bvc_vocoder_stream *voc = nullptr;
     hipGraphExec_t graph[8][2] = {};    // [k][vocoder parity]
     bool use_graph = true;
+    bool tick_flow = true;      // the ticks' recurrences on the persistent kernel where it is available (BVC_STREAM_FLOW=0: never)
     ~bvc_stream_codec() {
         for (auto &gk : graph) for (auto g : gk) if (g) (void)hipGraphExecDestroy(g);
         if (voc) bvc_vocoder_stream_destroy(voc);
@@ -2049,6 +2051,7 @@ int bvc_stream_codec_create(const bvc_model *m, int32_t B, int32_t hop_samples, 
     BVC_HIP_TRY(hipMemcpy(st->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
     if ((rc = bvc_vocoder_stream_create(m, B, st->kmax, &st->voc))) return rc;
     { const char *ng = getenv("BVC_STREAM_NO_GRAPH"); st->use_graph = !(ng && ng[0] == '1'); }
+    { const char *tf = getenv("BVC_STREAM_FLOW"); st->tick_flow = !(tf && tf[0] == '0'); }
     BVC_HIP_TRY(hipDeviceSynchronize());
     *out = st.release();
     return BVC_OK;
@@ -2084,8 +2087,14 @@ int bvc_stream_codec_tick(bvc_stream_codec *st, int32_t *n_frames, void *stream)
     int rc = BVC_OK;
     if (k > 0) {
         const int parity = st->voc->parity;
-        const bool warm = st->use_graph && s != nullptr && st->frames >= STREAM_WARM_FRAMES;     // (the default stream cannot be captured)
-        g_stream_tick = true;
+        // Which schedule?  Where the persistent recurrence kernel is available (flow_chains_static: the model's option, the
+        // residency census, the batch) the tick is launched eagerly and its two recurrences are one persistent launch each - at 256
+        // streams 1.53 ms per tick against 1.69 ms for the launch-per-layer recurrence, which gains nothing from a graph on the GPU
+        // side (1.68 eager / 1.70 replayed; the replay only saves host time).  Otherwise (recurrence = layers, no resident grid,
+        // BVC_STREAM_FLOW=0) the warm tick is one hipGraph of launch-per-layer kernels as before.  Same bits either way.
+        const bool tick_flow = st->tick_flow && flow_chains_static(st->m, B) != 0;
+        const bool warm = !tick_flow && st->use_graph && s != nullptr && st->frames >= STREAM_WARM_FRAMES;     // (the default stream cannot be captured)
+        g_stream_tick = true; g_tick_flow = tick_flow;
         if (!warm) {
             rc = stream_tick_body(st, k, s);
         } else {
@@ -2108,7 +2117,7 @@ int bvc_stream_codec_tick(bvc_stream_codec *st, int32_t *n_frames, void *stream)
                 st->voc->parity ^= 1; st->voc->frames += k;  // what stream_push() does on the host side
             }
         }
-        g_stream_tick = false;
+        g_stream_tick = false; g_tick_flow = false;
         if (rc) return rc;
     }
     sc_advance_kernel<<<1, 64, 0, s>>>(st->d_state, st->hop - c.hop * k);

@@ -179,8 +179,8 @@ class _DeviceView:
 
 class StreamingCodec:
     """BASELINE configs[4]: `batch` parallel streams, a fixed hop of new samples per tick, encode + decode of the frames
-    each hop completes in ONE library call (``bvc_stream_codec_tick``) that is replayed from a hipGraph once the
-    streams are warm.  State (sample buffer, both GRU states, the generator's activation history) lives in the library.
+    each hop completes in ONE library call (``bvc_stream_codec_tick``: one persistent launch per recurrence where that
+    kernel is available, else a hipGraph of launch-per-layer kernels replayed once the streams are warm).  State (sample buffer, both GRU states, the generator's activation history) lives in the library.
 
     ``push(x)`` with x (batch, hop) returns (codes (batch, k, z_dim), wav (batch, 256 k)) for the k frames completed;
     they equal the offline ``encode`` / ``decode`` of the whole signal on those frames (tests/test_gpu_streaming.py).
@@ -192,7 +192,7 @@ class StreamingCodec:
         self.dev = eng.device
         self.z = model.conf["z_dim"]
         self.spf = math.prod(model.conf["vocoder_config"]["upsample_rates"])
-        self.stream = torch.cuda.Stream(self.dev)          # a tick is captured into a hipGraph: not possible on the default stream
+        self.stream = torch.cuda.Stream(self.dev)          # a tick may be captured into a hipGraph: not possible on the default stream
         h = ctypes.c_void_p()
         with torch.cuda.device(self.dev):
             _abi.check(eng.lib.bvc_stream_codec_create(eng.handle, batch, hop, float(model.bits_per_frame(bitrate)), float(SCALING),

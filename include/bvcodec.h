@@ -227,9 +227,12 @@ int bvc_vocoder_stream_push(bvc_vocoder_stream *st, const float *d_mel, int32_t 
  * BVRNN.decode with carried GRU states and the incremental vocoder, i.e. encode + decode of exactly those frames, and equals
  * the offline bvc_encode / bvc_decode of the whole signal on them.  The caller writes the hop into d_in (B, hop_samples)
  * before the tick and finds d_codes (B, n_frames, z_dim) and d_wav (B, n_frames * 256) afterwards (buffers owned by the
- * state, fixed addresses).  From the 33rd frame on a tick is replayed from a hipGraph captured on first use (one per
- * frame count and vocoder parity; BVC_STREAM_NO_GRAPH=1 keeps eager launches).  scale / out_scale_div as in bvc_encode /
- * bvc_decode.  One in-flight tick per state; create allocates, tick does not (except the graph instantiation). */
+ * state, fixed addresses).  Schedule: where the persistent recurrence kernel is available (option "recurrence" not 1, the
+ * residency census passed, batch within its range) a tick is launched eagerly with ONE persistent launch per recurrence
+ * (BVC_STREAM_FLOW=0 turns that off); otherwise, from the 33rd frame on, a tick of launch-per-layer kernels is replayed from a
+ * hipGraph captured on first use (one per frame count and vocoder parity; BVC_STREAM_NO_GRAPH=1 keeps eager launches).  The
+ * bits are the same on every schedule.  scale / out_scale_div as in bvc_encode / bvc_decode.  One in-flight tick per state;
+ * create allocates, tick does not (except the graph instantiation). */
 typedef struct bvc_stream_codec bvc_stream_codec;
 int  bvc_stream_codec_create(const bvc_model *m, int32_t B, int32_t hop_samples, float bits_per_frame, float scale,
                              float out_scale_div, bvc_stream_codec **out);

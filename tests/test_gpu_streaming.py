@@ -145,15 +145,19 @@ def test_concurrent_stream_picker():
     assert len(bdist.concurrent_streams(2, dev)) == 2
 
 
-@pytest.mark.parametrize("B,graph", [(3, True), (40, True), (3, False), (256, True)])      # 256 streams: BASELINE configs[4]'s own size
-def test_whole_hop_codec_equals_offline_and_oracle(model, B, graph, monkeypatch):
-    """bvc_stream_codec_tick (BASELINE configs[4]: 441-sample hops, the tick replayed from a hipGraph once warm) against
-    the offline path AND, directly, against the CPU oracle."""
+@pytest.mark.parametrize("B,schedule", [(3, "flow"), (40, "flow"), (256, "flow"),               # 256 streams: BASELINE configs[4]'s own size
+                                        (3, "graph"), (40, "graph"), (256, "graph"), (3, "eager")])
+def test_whole_hop_codec_equals_offline_and_oracle(model, B, schedule, monkeypatch):
+    """bvc_stream_codec_tick (BASELINE configs[4]: 441-sample hops) against the offline path AND, directly, against the CPU
+    oracle, on each of its schedules: "flow" (the default: one persistent launch per recurrence), "graph" (launch-per-layer
+    kernels, the tick replayed from a hipGraph once warm) and "eager" (the same launches without the graph)."""
     from gpu_common import make_model
     from bvcodec import synth
     from bvcodec.streaming import StreamingCodec
     from oracle import codec as ocodec
-    if not graph:
+    if schedule != "flow":
+        monkeypatch.setenv("BVC_STREAM_FLOW", "0")
+    if schedule == "eager":
         monkeypatch.setenv("BVC_STREAM_NO_GRAPH", "1")
     _, conf, vr, ge = make_model(True, 1024)
     hop, hops = 441, 120                                            # 2.4 s: ~206 frames, > 170 of them replayed from graphs

@@ -33,7 +33,7 @@ else:                                          # default: one library call per h
     model.check_status()
 lat = np.array(lat[50:]) * 1e3
 print(json.dumps({"config": "BASELINE configs[4]: 256 streams x 20 ms hops @ 3 kbit/s, per-hop encode+decode",
-                  "schedule": "python-driven hop (round 1)" if python_path else ("bvc_stream_codec_tick: whole hop in one call, hipGraph-replayed" if os.environ.get("BVC_STREAM_NO_GRAPH") != "1" else "bvc_stream_codec_tick, eager launches"),
+                  "schedule": "python-driven hop (round 1)" if python_path else ("bvc_stream_codec_tick: whole hop in one call, persistent recurrence" if os.environ.get("BVC_STREAM_FLOW") != "0" else ("bvc_stream_codec_tick: launch-per-layer recurrence, hipGraph-replayed" if os.environ.get("BVC_STREAM_NO_GRAPH") != "1" else "bvc_stream_codec_tick: launch-per-layer recurrence, eager launches")),
                   "vocoder": "incremental (history buffers)" if incremental else "context recompute (26 frames)",
                   "p50_ms": round(float(np.percentile(lat, 50)), 3), "p99_ms": round(float(np.percentile(lat, 99)), 3),
                   "mean_ms": round(float(lat.mean()), 3), "hop_budget_ms": 20.0, "frames_per_hop": round(frames / hops, 3),
