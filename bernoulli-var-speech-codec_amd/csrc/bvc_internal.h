@@ -243,15 +243,17 @@ struct ConvWindow { long long in_bs, out_bs, row_begin, t_origin; };
 // in (B, Lin, cin) channels-last; out (B, Lout, cout).  Output row r reads input rows
 // r - (ks-1)*dil ... r  (rows outside [0,Lin) are zero).  res/acc have the layout of out.
 int conv_kernels_init();
-void set_amp16_enabled(bool on); // C = 16 AMP pairs: persistent kernel with swapped operands (default) or the generic one
-void set_amp8_enabled(bool on);  // C = 8 AMP pairs: two-rows-per-tile kernel (default) or the generic padded one
+// stage-specific AMP kernels a launch may take (per model): C = 8 pairs on the two-rows-per-tile kernel, C = 16 pairs on the persistent
+// kernel with swapped operands; without the bit the generic amp_pair_kernel runs (same bits)
+enum : unsigned { AMPK_C8 = 1u, AMPK_C16 = 2u, AMPK_ALL = 3u };
+unsigned amp_kernels_default();
 int launch_snakebeta_test(const float *x, long long n, float a, float ib, float *y, hipStream_t s);
 int launch_conv_mfma(const ConvLayer &c, const float *in, long long Lin, float *out, long long Lout,
                      int B, int epi, const float *res, const float *acc, float divisor, hipStream_t s,
                      const ConvWindow *win = nullptr);
 // one fused AMPBlock1 iteration: out = x + conv2(S2(conv1_dil(S1(x)))) (+acc, /divisor per epi); c2.dil == 1
 int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, long long L, float *out, int B, int epi,
-                    const float *acc, float divisor, hipStream_t s, const ConvWindow *win = nullptr);
+                    const float *acc, float divisor, hipStream_t s, const ConvWindow *win = nullptr, unsigned kernels = AMPK_ALL);
 // SnakeBeta -> causal conv C->1 (k taps) -> tanh -> / div -> first n_out samples
 int launch_conv_post(const float *in, long long Lin, int C, int ks, const float *w, const float *bias,
                      const float *act_a, const float *act_ib, float div, float *wav, long long n_out,

@@ -1,6 +1,7 @@
 // C ABI of libbvcodec_hip.so (include/bvcodec.h): model creation (weight upload + re-layout into
 // MFMA fragment order), workspace carving and the per-call kernel schedules of the
 // BVRNNCodecModel encode/decode path.  Host-side only; the kernels are in k_*.hip.
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -93,14 +94,15 @@ struct bvc_model {
     bool side_branch = false;   // measured SLOWER on MI355X (cross-branch graph dependencies + no spare L2->CU bandwidth): opt-in
     bool use_graph = true;
     bool fused_amp = true;
+    unsigned amp_kernels = AMPK_ALL;   // stage-specific generator kernels in use (options vocoder_full_tiles / vocoder_c16_kernel)
     bool precomp_pz = true;     // decode: the phi_z halves of dec.0 and of the GRU input product are batched over all frames
     int mtw = 1;                // 16-row tiles per workgroup in the recurrent kernels (BVC_MTW = 1 | 2 | 4)
     // persistent recurrence (k_flow.hip): hop tables of encode / decode, resident in device memory
     // recurrence schedule: RS_PERSISTENT one launch per call (k_flow.hip), RS_LAYERS one launch per layer (hipGraph replay),
     // RS_AUTO (default) persistent while calls come one at a time, layers while calls of several streams overlap
     int recurrence = 2;         // BVC_RECURRENCE=persistent|layers|auto, bvc_model_set_option("recurrence")
-    mutable bool flow_resident = false; // the residency census found a full persistent grid co-resident on this device
-    mutable bool census_due = false;    // a recurrence time-out was seen: the census runs again before the next persistent launch (another
+    mutable std::atomic<bool> flow_resident{false}; // the residency census found a full persistent grid co-resident on this device
+    mutable std::atomic<bool> census_due{false};    // a recurrence time-out was seen: the census runs again before the next persistent launch (another
                                         // tenant may have arrived after bvc_model_create: the model then moves to the layer schedule)
     mutable hipStream_t census_stream = nullptr;
     mutable unsigned *census_ctr = nullptr;
@@ -1536,7 +1538,7 @@ int run_vocoder(const bvc_model *m, const Workspace &w, const float *d_mel, int 
                     if (c.n_resk == 1) epi = CE_RES;
                 }
                 if (m->fused_amp) {
-                    if ((rc = launch_amp_pair(ap.c1, ap.c2, cur, L, dst, B, epi, w.XS, (float)c.n_resk, s))) return rc;
+                    if ((rc = launch_amp_pair(ap.c1, ap.c2, cur, L, dst, B, epi, w.XS, (float)c.n_resk, s, nullptr, m->amp_kernels))) return rc;
                 } else if ((rc = launch_conv_mfma(ap.c2, w.U, L, dst, L, B, epi, cur, w.XS, (float)c.n_resk, s))) return rc;
                 cur = dst;
             }
@@ -1647,7 +1649,7 @@ int stream_push(bvc_vocoder_stream *st, const float *d_mel, int k, float div, fl
                     epi = (j == 0) ? CE_RES : (j + 1 < c.n_resk ? CE_RES_ACC : CE_RES_ACC_DIV);
                     if (c.n_resk == 1) epi = CE_RES;
                 }
-                if ((rc = launch_amp_pair(ap.c1, ap.c2, cur, L, dst, B, epi, XS.buf[p], (float)c.n_resk, s, &w))) return rc;
+                if ((rc = launch_amp_pair(ap.c1, ap.c2, cur, L, dst, B, epi, XS.buf[p], (float)c.n_resk, s, &w, m->amp_kernels))) return rc;
                 cur = dst;
             }
         }
@@ -1786,6 +1788,7 @@ int bvc_model_create(const bvc_config *cfg, const bvc_tensor *tensors, int32_t n
         if (mw && (mw[0] == '2' || mw[0] == '4')) m->mtw = mw[0] - '0';
         const char *ua = getenv("BVC_UNFUSED_AMP");
         m->fused_amp = !(ua && ua[0] == '1');
+        m->amp_kernels = amp_kernels_default();
         const char *np = getenv("BVC_NO_PRECOMP");
         m->precomp_pz = !(np && np[0] == '1') && !m->side_branch;
     }
@@ -2159,12 +2162,12 @@ int bvc_model_set_option(bvc_model *m, const char *name, int32_t value) {
         m->flow_debug_nofill = value != 0;
         return BVC_OK;
     }
-    if (strcmp(name, "vocoder_c16_kernel") == 0) {         // 1 (default): C = 16 AMP pairs on the persistent kernel; 0: generic kernel.  Same bits;
-        set_amp16_enabled(value != 0);                     // process-wide, like vocoder_full_tiles
+    if (strcmp(name, "vocoder_c16_kernel") == 0) {         // 1 (default): C = 16 AMP pairs on the persistent kernel; 0: generic kernel.  Same bits
+        m->amp_kernels = value ? (m->amp_kernels | AMPK_C16) : (m->amp_kernels & ~AMPK_C16);
         return BVC_OK;
     }
-    if (strcmp(name, "vocoder_full_tiles") == 0) {         // 1 (default): C = 8 AMP pairs on the two-rows-per-tile kernel; 0: generic kernel.
-        set_amp8_enabled(value != 0);                      // Process-wide (a validation switch: both give the same bits)
+    if (strcmp(name, "vocoder_full_tiles") == 0) {         // 1 (default): C = 8 AMP pairs on the two-rows-per-tile kernel; 0: generic kernel.  Same bits
+        m->amp_kernels = value ? (m->amp_kernels | AMPK_C8) : (m->amp_kernels & ~AMPK_C8);
         return BVC_OK;
     }
     set_error("bvc_model_set_option: unknown option '%s'", name);

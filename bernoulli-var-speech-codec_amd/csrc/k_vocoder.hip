@@ -585,10 +585,10 @@ __global__ __launch_bounds__(256, OCC) void amp_pair_kernel(AmpArgs a) {
 // stored de-interleaved to match: row rho = 2d*blk + half*d + i sits at position half * H + blk*d + i, which puts the A
 // operand of pair m, k-step k' = 2a + b at position m + a*d + b*H: lane stride = one row (S = 10 floats: conflict-free
 // ds_read_b32), one compile-time offset per k-step.
-static bool g_amp8_enabled = getenv("BVC_NO_AMP8") == nullptr;       // bvc_model_set_option("vocoder_full_tiles"): validation switch, process-wide
-void set_amp8_enabled(bool on) { g_amp8_enabled = on; }
-static bool g_amp16_enabled = getenv("BVC_NO_AMP16") == nullptr;     // bvc_model_set_option("vocoder_c16_kernel"): the same kind of switch for the C = 16 stage
-void set_amp16_enabled(bool on) { g_amp16_enabled = on; }
+// which of the stage-specific kernels a model starts with (bvc_model_set_option "vocoder_full_tiles" / "vocoder_c16_kernel": validation switches)
+unsigned amp_kernels_default() {
+    return (getenv("BVC_NO_AMP8") == nullptr ? AMPK_C8 : 0u) | (getenv("BVC_NO_AMP16") == nullptr ? AMPK_C16 : 0u);
+}
 
 template <int D>
 __device__ __forceinline__ int pair_row(int m) { return (m / D) * (2 * D) + m % D; }
@@ -1099,7 +1099,7 @@ static int launch_amp_t(AmpArgs a, int B, hipStream_t s) {
 }
 
 int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, long long L, float *out, int B, int epi,
-                    const float *acc, float divisor, hipStream_t s, const ConvWindow *win) {
+                    const float *acc, float divisor, hipStream_t s, const ConvWindow *win, unsigned kernels) {
     if (B <= 0 || L <= 0) return BVC_OK;
     if (c1.cin != c1.cout || c2.cin != c1.cin || c2.ks != c1.ks || c2.dil != 1 || !c1.act_a || !c2.act_a) {
         set_error("amp_pair: unsupported layer pair");
@@ -1123,7 +1123,7 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
     if (win && c1.cin == 64 && new_rows <= 32 - (c1.ks - 1)) return launch_amp_t<64, 2, 2, true, 4>(a, B, s);      // 32 rows, waves split the columns
     if (win && c1.cin == 64 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<64, 1, 2, true>(a, B, s);
     if (win && c1.cin == 32 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<32, 1, 3, true>(a, B, s);
-    if (c1.cin == 8 && c1.wp2 && c2.wp2 && g_amp8_enabled) {           // full-tile form of the C = 8 stage
+    if (c1.cin == 8 && c1.wp2 && c2.wp2 && (kernels & AMPK_C8)) {           // full-tile form of the C = 8 stage
         AmpArgs a8 = a;
         a8.w1 = c1.wp2; a8.w2 = c2.wp2;
         // tile shapes from a measured sweep (16-pair tiles per wave x register budget): <2, 2> 2.07 ms per step for the stage,
@@ -1142,7 +1142,7 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
         }
         case 32: return launch_amp_t<32, 4, 3, true>(a, B, s);     // (waves along the columns, CS = 2 with 4 or 8 row tiles: 4.64 / 4.41 against 4.48)
         case 16: {
-            if (g_amp16_enabled && !win) {                  // offline sweep: the persistent C = 16 kernel
+            if ((kernels & AMPK_C16) && !win) {                  // offline sweep: the persistent C = 16 kernel
                 // four row tiles per wave (256 rows per workgroup): 2.82 (generic kernel) -> 2.62 ms per step for the stage; two tiles 2.82,
                 // six (KS <= 7) 2.60
                 const int rc16 = launch_amp16<4>(a, B, s);

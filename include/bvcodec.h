@@ -31,8 +31,10 @@
  *  - one in-flight call per (model, workspace): calls on different streams with different
  *    workspaces may overlap (persistent recurrence kernels of overlapping calls run one after the
  *    other, everything else concurrently; with the default "recurrence" = auto overlapping calls take
- *    the launch-per-layer schedule, whose kernels interleave); models are immutable after creation;
- *    the library is not re-entrant on ONE model from several host threads at once.
+ *    the launch-per-layer schedule, whose kernels interleave).  Several host threads may issue calls on ONE model
+ *    at once, each with its own workspace and stream (the model's graph cache, the persistent launches' ticket and
+ *    the census are guarded inside the library); a model's weights are immutable after creation, and its options
+ *    (bvc_model_set_option) must not be changed while another thread is issuing calls on it.
  */
 #ifndef BVCODEC_H
 #define BVCODEC_H
@@ -114,10 +116,10 @@ void bvc_model_destroy(bvc_model *m);
  *                 residency census at bvc_model_create found that a full persistent grid is not co-resident on this device.
  *   "vocoder_full_tiles": 1 (default) = the eight-channel generator stage runs on the kernel that packs two output rows into
  *                 one MFMA tile, 0 = on the generic kernel (half of every tile is channel padding).  Same bits either way;
- *                 a validation switch, and process-wide rather than per model.
+ *                 a validation switch (per model, like every option).
  *   "vocoder_c16_kernel": 1 (default) = the sixteen-channel generator stage runs offline on its persistent kernel (weights in
  *                 registers, next tile's rows under the current tile's convs, 16-byte epilogues), 0 = on the generic kernel.
- *                 Same bits either way; process-wide, like "vocoder_full_tiles".
+ *                 Same bits either way; per model.
  *   "decode_fold": 1 (default) = the persistent DECODE kernel runs phi_x.0((dec.6(u) - mean) / std) - three maps with no
  *                 non-linearity between them (bvrnn.py:80, :226) - as ONE affine map of u (folded in float64 at model creation):
  *                 one wide layer instead of two narrow hops per frame; dec.6(u), the decoder's output, is then one batched GEMM

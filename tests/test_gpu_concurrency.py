@@ -63,7 +63,7 @@ def test_four_stream_schedule_equals_serial(recurrence):
 
 
 def test_two_models_on_two_host_threads():
-    """include/bvcodec.h: models are independent, one model is not re-entrant.  Two models (different weights), each driven by its
+    """include/bvcodec.h: models are independent.  Two models (different weights), each driven by its
     own host thread on its own stream (ctypes releases the GIL inside a call, so the library calls really overlap on the host):
     the persistent launches of the two go through the process-wide ticket one after the other, everything else overlaps; both
     threads must get bit for bit what the same calls give from one thread."""
@@ -182,3 +182,52 @@ def test_large_batch_on_interleaved_chains_equals_layer_schedule(B, frames):
     r = oc.encode(x[pick].cpu(), 3000, full=True)
     mism = codes[pick].cpu() != r["codes"]
     assert not bool((mism & ((r["prob"] - 0.5).abs() > 1e-5)).any())
+
+
+@pytest.mark.parametrize("recurrence", ["auto", "persistent", "layers"])
+def test_one_model_on_two_host_threads(recurrence):
+    """include/bvcodec.h: several host threads may issue calls on ONE model at once, each with its own workspace and stream
+    (the facade keeps one workspace per stream).  Two threads, different inputs, every schedule: each thread must get bit for
+    bit what the same calls give from one thread - also under `auto`, where the two threads' calls see each other as company
+    and change schedule on the way (one order of summation: same bits)."""
+    import threading
+    from gpu_common import make_model
+    from bvcodec import synth
+    model = make_model(True, 1024, seed=1234)[0]
+    B, L, rounds = 40, int(22050 * 0.8), 5
+    xs = [synth.synthetic_speech(B, L, seed=300 + i, kind="speech").to(DEV) for i in range(2)]
+    try:
+        model.set_recurrence("persistent")
+        ref = []
+        for x in xs:
+            codes = model.encode(x, 3000)
+            ref.append((codes, model.decode(codes, L)))
+        torch.cuda.synchronize(DEV)
+        model.set_recurrence(recurrence)
+        streams = [torch.cuda.Stream(DEV) for _ in xs]
+        results, errors = [[] for _ in xs], []
+
+        def worker(i):
+            try:
+                with torch.cuda.stream(streams[i]):
+                    for _ in range(rounds):
+                        codes = model.encode(xs[i], 3000)
+                        results[i].append((codes, model.decode(codes, L)))
+                streams[i].synchronize()
+            except Exception as e:                               # noqa: BLE001 - reported by the assert below
+                errors.append((i, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(120)
+        torch.cuda.synchronize(DEV)
+        assert not errors, errors
+        for i in range(2):
+            assert len(results[i]) == rounds
+            for codes, wav in results[i]:
+                assert torch.equal(codes, ref[i][0]) and torch.equal(wav, ref[i][1])
+        model.check_status()
+    finally:
+        model.set_recurrence("auto")
