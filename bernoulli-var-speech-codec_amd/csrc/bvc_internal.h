@@ -192,7 +192,10 @@ struct FlowArgs {
 };
 int flow_kernels_init();
 int flow_perh(int h_dim);
-int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, bool fill, hipStream_t s);
+int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, bool fill, hipStream_t s, bool args_resident = false);
+// sentinel fill of the flow region + initial state into its first buffer + the device copy of the arguments, in one kernel
+int launch_flow_prepare(const FlowArgs &a, FlowArgs *d_args, unsigned *flow, long long n_flow, long long n_h0, const float *d_h0, int B, int H,
+                        hipStream_t s);
 int launch_flow_census(unsigned *ctr, int grid, unsigned spin_limit, hipStream_t s);   // ctr[0] arrivals, ctr[1] workgroups that gave up
 int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s);
 

@@ -1156,11 +1156,7 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, int chains, co
         BVC_HIP_TRY(hipStreamIsCapturing(s, &cs));
         if (cs != hipStreamCaptureStatusNone) { set_error("the persistent recurrence cannot be captured into a graph"); return BVC_EINVAL; }
     }
-    if ((rc = launch_fill_u32(reinterpret_cast<unsigned *>(w.flow), FLOW_POISON, (long long)FB_COUNT * 2 * (long long)w.flow_slot, s))) return rc;
     float *h0p = flow_buf(w, FB_H, 0);
-    if ((rc = launch_fill(h0p, 0.0f, (long long)mt16 * H, s))) return rc;
-    if (d_h0 && (rc = launch_repack_rows(d_h0, h0p, H, B, H, 0, s))) return rc;
-    if (d_all_h && (rc = launch_repack_rows(h0p, d_all_h, (long long)T * H, B, H, 1, s))) return rc;     // all_h[:, 0] = h0
     FlowArgs a;
     memset(&a, 0, sizeof(a));
     flow_layers(m, encode, &a);
@@ -1190,6 +1186,18 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, int chains, co
         a.probe_wg = getenv("BVC_PROBE_WG") ? atoi(getenv("BVC_PROBE_WG")) : 0;
         a.probe_wave = getenv("BVC_PROBE_WAVE") ? atoi(getenv("BVC_PROBE_WAVE")) & 7 : 0;
     }
+    // the flow region filled with the sentinel, h(-1) in its first buffer (FB_H, parity 0, at the start of the region) and the device copy
+    // of the arguments: one kernel (a misaligned initial state takes the three separate ones)
+    const long long n_flow = (long long)FB_COUNT * 2 * (long long)w.flow_slot;
+    const bool fused_prepare = !d_h0 || (reinterpret_cast<uintptr_t>(d_h0) & 15) == 0;
+    if (fused_prepare) {
+        if ((rc = launch_flow_prepare(a, w.flow_args, reinterpret_cast<unsigned *>(w.flow), n_flow, (long long)mt16 * H, d_h0, B, H, s))) return rc;
+    } else {
+        if ((rc = launch_fill_u32(reinterpret_cast<unsigned *>(w.flow), FLOW_POISON, n_flow, s))) return rc;
+        if ((rc = launch_fill(h0p, 0.0f, (long long)mt16 * H, s))) return rc;
+        if ((rc = launch_repack_rows(d_h0, h0p, H, B, H, 0, s))) return rc;
+    }
+    if (d_all_h && (rc = launch_repack_rows(h0p, d_all_h, (long long)T * H, B, H, 1, s))) return rc;     // all_h[:, 0] = h0
     {
         std::lock_guard<std::mutex> lk(g_flow_mu);
         int dev = 0;
@@ -1203,7 +1211,7 @@ int run_flow(const bvc_model *m, const Workspace &w, bool encode, int chains, co
             if (f.pending) { BVC_HIP_TRY(hipStreamWaitEvent(s, f.ev, 0)); f.pending = false; }
         ProbeScope probe(PK_LINEAR, s);
         static const bool fill = !(getenv("BVC_FLOW_FILL") && getenv("BVC_FLOW_FILL")[0] == '0');
-        if ((rc = launch_flow(a, w.flow_args, m->flow_perh, encode, fill && !m->flow_debug_nofill && a.MG == 1, s))) return rc;
+        if ((rc = launch_flow(a, w.flow_args, m->flow_perh, encode, fill && !m->flow_debug_nofill && a.MG == 1, s, fused_prepare))) return rc;
         BVC_HIP_TRY(hipEventRecord(ev, s));
         ++g_flow_n[dev];
     }
@@ -1561,6 +1569,7 @@ int run_vocoder(const bvc_model *m, const Workspace &w, const float *d_mel, int 
 struct StreamTensor { float *buf[2]; int C, H, rate; long long rows; };
 struct RotEntry { float *buf[2]; long long bs; int C, H, rate, pad_; };
 
+// (one workgroup per (tensor, stream) with four 16-byte pieces in flight per thread measured slower: 67 against 56 us at 256 streams)
 __global__ __launch_bounds__(256) void stream_rotate_kernel(const RotEntry *__restrict__ tab, int k, int parity) {
     const RotEntry e = tab[blockIdx.z];
     const long long n4 = (long long)e.H * e.C / 4;

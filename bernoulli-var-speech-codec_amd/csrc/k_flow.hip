@@ -1277,6 +1277,46 @@ __global__ void fill_u32_kernel(unsigned *p, unsigned v, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// Everything a persistent launch needs in place, as ONE kernel: the flow region filled with the sentinel, its first buffer - h of frame -1:
+// n_h0 = mt16 * H floats in operand-fragment order - set to the caller's initial state (natural (B, H) rows; null: zero; padding rows
+// zero), and the device copy of the arguments.
+__global__ __launch_bounds__(256) void flow_prepare_kernel(FlowArgs *dst, FlowArgs v, unsigned *flow, long long n_flow, long long n_h0,
+                                                           const float *__restrict__ h0, int B, int H) {
+    if (blockIdx.x == 0) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(&v);
+        unsigned *d = reinterpret_cast<unsigned *>(dst);
+        for (unsigned i = threadIdx.x; i < sizeof(FlowArgs) / 4; i += blockDim.x) d[i] = src[i];
+    }
+    const int ntile = H >> 4;
+    uint4 *flow4 = reinterpret_cast<uint4 *>(flow);
+    const long long n4 = n_flow >> 2, h4 = n_h0 >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        uint4 o = {FLOW_POISON, FLOW_POISON, FLOW_POISON, FLOW_POISON};
+        if (i < h4) {                                      // 16 bytes of a fragment-packed block: columns n .. n + 3 of row m
+            const long long tile = i >> 6;
+            const int lane = (int)(i & 63);
+            const int m = (int)(tile / ntile) * 16 + (lane & 15), n = (int)(tile % ntile) * 16 + (lane >> 4) * 4;
+            float4 hv = {0.f, 0.f, 0.f, 0.f};
+            if (h0 && m < B) hv = *reinterpret_cast<const float4 *>(h0 + (long long)m * H + n);
+            o = {__float_as_uint(hv.x), __float_as_uint(hv.y), __float_as_uint(hv.z), __float_as_uint(hv.w)};
+        }
+        flow4[i] = o;
+    }
+}
+
+int launch_flow_prepare(const FlowArgs &a, FlowArgs *d_args, unsigned *flow, long long n_flow, long long n_h0, const float *d_h0, int B, int H,
+                        hipStream_t s) {
+    if (n_flow % 4 || n_h0 % 4 || H % 16 || n_h0 > n_flow || (d_h0 && (reinterpret_cast<uintptr_t>(d_h0) & 15))) {
+        set_error("flow_prepare: unaligned flow region or initial state");
+        return BVC_EINVAL;
+    }
+    const long long n4 = n_flow / 4;
+    const int grid = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(flow_prepare_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, d_args, a, flow, n_flow, n_h0, d_h0, B, H);
+    BVC_HIP_TRY(hipGetLastError());
+    return BVC_OK;
+}
+
 int launch_fill_u32(unsigned *p, unsigned v, long long n, hipStream_t s) {
     if (n <= 0) return BVC_OK;
     const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
@@ -1346,9 +1386,9 @@ static void flow_launch_t(const FlowArgs *d_a, bool encode, bool fill, int grid,
 // (A 4-wave form - bvrnn_flow_kernel<16, ., false, 4>: one wave per SIMD, 214 VGPRs, so that the vocoder of the same or of
 // another call could share the CUs with the recurrence - was built and measured: correct, but 27 % slower per frame, and with
 // four batches in flight 5,120 audio-s/s against 5,700.  NW stays a template parameter; only the 8-wave form is instantiated.)
-int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, bool fill, hipStream_t s) {
+int launch_flow(const FlowArgs &a, FlowArgs *d_args, int perh, bool encode, bool fill, hipStream_t s, bool args_resident) {
     static_assert(sizeof(FlowArgs) % 4 == 0, "FlowArgs is copied in dwords");
-    hipLaunchKernelGGL(flow_set_args_kernel, dim3(1), dim3(256), 0, s, d_args, a);
+    if (!args_resident) hipLaunchKernelGGL(flow_set_args_kernel, dim3(1), dim3(256), 0, s, d_args, a);
     const FlowArgs *d_a = d_args;
     if (a.MG > 1) {                                        // interleaved chains: more utterance groups than workgroup slots per feature tile
         if (perh != 8) { set_error("launch_flow: interleaved chains are built for h_dim 1024 only"); return BVC_EINVAL; }

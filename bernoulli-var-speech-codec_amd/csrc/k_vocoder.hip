@@ -1122,7 +1122,8 @@ int launch_amp_pair(const ConvLayer &c1, const ConvLayer &c2, const float *x, lo
     const long long new_rows = L - a.row_begin;
     if (win && c1.cin == 64 && new_rows <= 32 - (c1.ks - 1)) return launch_amp_t<64, 2, 2, true, 4>(a, B, s);      // 32 rows, waves split the columns
     if (win && c1.cin == 64 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<64, 1, 2, true>(a, B, s);
-    if (win && c1.cin == 32 && new_rows <= 2 * (64 - (c1.ks - 1))) return launch_amp_t<32, 1, 3, true>(a, B, s);
+    static const int s32 = getenv("BVC_AMP32S") ? atoi(getenv("BVC_AMP32S")) : 3;       // (3 tiles of 64 rows against one of 256 for a two-frame hop: 1.53 -> 1.47 ms per tick at 256 streams)
+    if (win && c1.cin == 32 && new_rows <= s32 * (64 - (c1.ks - 1))) return launch_amp_t<32, 1, 3, true>(a, B, s);
     if (c1.cin == 8 && c1.wp2 && c2.wp2 && (kernels & AMPK_C8)) {           // full-tile form of the C = 8 stage
         AmpArgs a8 = a;
         a8.w1 = c1.wp2; a8.w2 = c2.wp2;
