@@ -1591,6 +1591,11 @@ __global__ __launch_bounds__(256) void stream_rows_in_kernel(const float *__rest
 struct bvc_vocoder_stream {
     const bvc_model *m = nullptr;
     int B = 0, kmax = 0, parity = 0;
+    // slide: ONE buffer per tensor with room for cap_frames frames; the window of a hop starts `cursor` frames into it and the history is
+    // moved back to the front only when the room is used up (every cap_frames / kmax hops at least) instead of after every hop.  The
+    // addresses of a hop then change from hop to hop: not for a hop that is replayed from a graph (bvc_stream_codec's eager ticks only).
+    bool slide = false;
+    int cursor = 0, cap_frames = 0;
     int64_t frames = 0;
     float *pool = nullptr;
     size_t pool_floats = 0;
@@ -1616,15 +1621,17 @@ int stream_push(bvc_vocoder_stream *st, const float *d_mel, int k, float div, fl
     const int B = st->B, p = st->parity;
     int rc;
     auto bs = [](const StreamTensor &t) { return t.rows * t.C; };
+    // first row of this hop's window of a tensor (its history; the new rows follow)
+    auto at = [&](const StreamTensor &t) { return t.buf[p] + (long long)st->cursor * t.rate * t.C; };
     // new mel rows behind the history
     stream_rows_in_kernel<<<dim3((unsigned)((k * st->mel.C + 255) / 256), B), 256, 0, s>>>(
-        d_mel, (long long)k * st->mel.C, st->mel.buf[p] + (long long)st->mel.H * st->mel.C, bs(st->mel), (long long)k * st->mel.C);
+        d_mel, (long long)k * st->mel.C, at(st->mel) + (long long)st->mel.H * st->mel.C, bs(st->mel), (long long)k * st->mel.C);
     BVC_HIP_TRY(hipGetLastError());
     // conv_pre: mel rows [Hm, Hm+k) -> y0 rows [Hy, Hy+k)
     {
         ConvWindow w{bs(st->mel), bs(st->y0), st->mel.H, 0};
-        float *out = st->y0.buf[p] + (long long)(st->y0.H - st->mel.H) * st->y0.C;
-        if ((rc = launch_conv_mfma(m->conv_pre, st->mel.buf[p], st->mel.H + k, out, st->mel.H + k, B, CE_STORE, nullptr,
+        float *out = at(st->y0) + (long long)(st->y0.H - st->mel.H) * st->y0.C;
+        if ((rc = launch_conv_mfma(m->conv_pre, at(st->mel), st->mel.H + k, out, st->mel.H + k, B, CE_STORE, nullptr,
                                    nullptr, 1.0f, s, &w))) return rc;
     }
     const StreamTensor *prev = &st->y0;
@@ -1637,8 +1644,8 @@ int stream_push(bvc_vocoder_stream *st, const float *d_mel, int k, float div, fl
             const long long hq = X.H / u;                              // history rows of the view
             const long long nq = rate_prev * k;                        // new view rows
             ConvWindow w{bs(*prev), bs(X), hq, 0};
-            const float *in = prev->buf[p] + (long long)(prev->H - hq) * prev->C;
-            if ((rc = launch_conv_mfma(m->ups[i], in, hq + nq, X.buf[p], hq + nq, B, CE_STORE, nullptr, nullptr, 1.0f, s, &w))) return rc;
+            const float *in = at(*prev) + (long long)(prev->H - hq) * prev->C;
+            if ((rc = launch_conv_mfma(m->ups[i], in, hq + nq, at(X), hq + nq, B, CE_STORE, nullptr, nullptr, 1.0f, s, &w))) return rc;
         }
         const long long L = X.H + (long long)X.rate * k;
         // t_origin only decides which rows lie before the start of the signal; from STREAM_WARM_FRAMES frames on none
@@ -1647,18 +1654,18 @@ int stream_push(bvc_vocoder_stream *st, const float *d_mel, int k, float div, fl
         ConvWindow w{bs(X), bs(X), X.H, (long long)X.rate * fr - X.H};
         for (int j = 0; j < c.n_resk; ++j) {
             const StreamTensor &P = st->P[i * c.n_resk + j], &Q = st->Q[i * c.n_resk + j];
-            const float *cur = X.buf[p];
+            const float *cur = at(X);
             for (int d = 0; d < 3; ++d) {
                 const AmpPair &ap = m->amp[i][j][d];
                 float *dst;
                 int epi = CE_RES;
-                if (d < 2) dst = (d == 0) ? P.buf[p] : Q.buf[p];
+                if (d < 2) dst = (d == 0) ? at(P) : at(Q);
                 else {
-                    dst = XS.buf[p];
+                    dst = at(XS);
                     epi = (j == 0) ? CE_RES : (j + 1 < c.n_resk ? CE_RES_ACC : CE_RES_ACC_DIV);
                     if (c.n_resk == 1) epi = CE_RES;
                 }
-                if ((rc = launch_amp_pair(ap.c1, ap.c2, cur, L, dst, B, epi, XS.buf[p], (float)c.n_resk, s, &w, m->amp_kernels))) return rc;
+                if ((rc = launch_amp_pair(ap.c1, ap.c2, cur, L, dst, B, epi, at(XS), (float)c.n_resk, s, &w, m->amp_kernels))) return rc;
                 cur = dst;
             }
         }
@@ -1667,12 +1674,20 @@ int stream_push(bvc_vocoder_stream *st, const float *d_mel, int k, float div, fl
     }
     {
         ConvWindow w{bs(*prev), 0, prev->H, 0};
-        if ((rc = launch_conv_post(prev->buf[p], prev->H + rate_prev * k, m->post_c, m->post_ks, m->post_w, m->post_b,
+        if ((rc = launch_conv_post(at(*prev), prev->H + rate_prev * k, m->post_c, m->post_ks, m->post_w, m->post_b,
                                    m->post_a, m->post_ib, div, d_wav, rate_prev * k, B, s, &w))) return rc;
     }
-    stream_rotate_kernel<<<dim3((unsigned)((st->max_hc4 + 255) / 256), B, st->n_ten), 256, 0, s>>>(st->d_tab, k, p);
+    if (!st->slide) {
+        stream_rotate_kernel<<<dim3((unsigned)((st->max_hc4 + 255) / 256), B, st->n_ten), 256, 0, s>>>(st->d_tab, k, p);
+        st->parity ^= 1;
+    } else {
+        st->cursor += k;                                     // the next hop's window starts behind this hop's rows
+        if (st->cursor + st->kmax > st->cap_frames) {        // no room for another hop: history back to the front (the twin buffer IS the buffer)
+            stream_rotate_kernel<<<dim3((unsigned)((st->max_hc4 + 255) / 256), B, st->n_ten), 256, 0, s>>>(st->d_tab, st->cursor, 0);
+            st->cursor = 0;
+        }
+    }
     BVC_HIP_TRY(hipGetLastError());
-    st->parity ^= 1;
     st->frames += k;
     return BVC_OK;
 }
@@ -1944,7 +1959,13 @@ int bvc_decode(const bvc_model *m, const float *d_codes, int32_t B, int64_t T, i
     return run_vocoder(m, w, w.mel, B, T, length, out_scale_div, d_wav, -1, nullptr, nullptr, nullptr, s);
 }
 
+static int vocoder_stream_create(const bvc_model *m, int32_t B, int32_t max_frames_per_push, bool slide, bvc_vocoder_stream **out);
+
 int bvc_vocoder_stream_create(const bvc_model *m, int32_t B, int32_t max_frames_per_push, bvc_vocoder_stream **out) {
+    return vocoder_stream_create(m, B, max_frames_per_push, false, out);
+}
+
+static int vocoder_stream_create(const bvc_model *m, int32_t B, int32_t max_frames_per_push, bool slide, bvc_vocoder_stream **out) {
     if (!m || !out || B <= 0 || max_frames_per_push <= 0) { set_error("bvc_vocoder_stream_create: bad arguments"); return BVC_EINVAL; }
     const bvc_config &c = m->cfg;
     // the history must cover every receptive field and stay aligned with the transposed-conv views
@@ -1964,10 +1985,13 @@ int bvc_vocoder_stream_create(const bvc_model *m, int32_t B, int32_t max_frames_
     if (m->post_ks - 1 > STREAM_H) { set_error("streaming vocoder: conv_post kernel exceeds the history"); return BVC_EINVAL; }
     std::unique_ptr<bvc_vocoder_stream> st(new bvc_vocoder_stream());
     st->m = m; st->B = B; st->kmax = max_frames_per_push;
-    auto mk = [&](int C, int H, int r) { StreamTensor t; t.buf[0] = t.buf[1] = nullptr; t.C = C; t.H = H; t.rate = r; t.rows = H + (long long)r * max_frames_per_push; return t; };
+    st->slide = slide;
+    st->cap_frames = slide ? 16 * max_frames_per_push : max_frames_per_push;      // frames of room behind the history
+    const long long room = st->cap_frames;
+    auto mk = [&](int C, int H, int r) { StreamTensor t; t.buf[0] = t.buf[1] = nullptr; t.C = C; t.H = H; t.rate = r; t.rows = H + (long long)r * room; return t; };
     st->mel = mk(c.num_mels, (m->conv_pre.ks - 1) * m->conv_pre.dil, 1);
     st->y0 = mk(c.upsample_initial_channel, STREAM_H / c.up_rates[0], 1);
-    if (st->y0.H < st->mel.H) st->y0.H = st->mel.H, st->y0.rows = st->y0.H + max_frames_per_push;
+    if (st->y0.H < st->mel.H) st->y0.H = st->mel.H, st->y0.rows = st->y0.H + room;
     rate = 1;
     for (int i = 0; i < c.n_up; ++i) {
         rate *= c.up_rates[i];
@@ -1979,7 +2003,12 @@ int bvc_vocoder_stream_create(const bvc_model *m, int32_t B, int32_t max_frames_
     for (auto *v : {&st->X, &st->XS, &st->P, &st->Q})
         for (auto &t : *v) all.push_back(&t);
     size_t total = 0;
-    for (auto *t : all) total += 2 * (size_t)B * t->rows * t->C;
+    const int copies = slide ? 1 : 2;
+    for (auto *t : all) {
+        total += copies * (size_t)B * t->rows * t->C;
+        // moving the history back to the front must not overlap itself: it happens with more than cap_frames - 2 kmax frames behind it
+        if (slide && (long long)(st->cap_frames - 2 * st->kmax + 1) * t->rate < t->H) { set_error("streaming vocoder: sliding window too short for its history"); return BVC_EINVAL; }
+    }
     if (hipMalloc(reinterpret_cast<void **>(&st->pool), total * sizeof(float)) != hipSuccess) {
         (void)hipGetLastError();
         set_error("streaming vocoder: cannot allocate %zu bytes of history buffers", total * sizeof(float));
@@ -1989,7 +2018,8 @@ int bvc_vocoder_stream_create(const bvc_model *m, int32_t B, int32_t max_frames_
     size_t off = 0;
     std::vector<RotEntry> tab;
     for (auto *t : all) {
-        for (int q = 0; q < 2; ++q) { t->buf[q] = st->pool + off; off += (size_t)B * t->rows * t->C; }
+        for (int q = 0; q < copies; ++q) { t->buf[q] = st->pool + off; off += (size_t)B * t->rows * t->C; }
+        if (slide) t->buf[1] = t->buf[0];
         RotEntry e; e.buf[0] = t->buf[0]; e.buf[1] = t->buf[1]; e.bs = t->rows * t->C; e.C = t->C; e.H = t->H; e.rate = t->rate; e.pad_ = 0;
         tab.push_back(e);
         if ((t->H * t->C) % 4) { set_error("streaming vocoder: history of a tensor is not a multiple of 4 floats"); return BVC_EINVAL; }
@@ -2008,7 +2038,7 @@ void bvc_vocoder_stream_destroy(bvc_vocoder_stream *st) { delete st; }
 int bvc_vocoder_stream_reset(bvc_vocoder_stream *st, void *stream) {
     if (!st) { set_error("null stream state"); return BVC_EINVAL; }
     BVC_HIP_TRY(hipMemsetAsync(st->pool, 0, st->pool_floats * sizeof(float), (hipStream_t)stream));
-    st->parity = 0; st->frames = 0;
+    st->parity = 0; st->frames = 0; st->cursor = 0;
     return BVC_OK;
 }
 
@@ -2061,9 +2091,13 @@ int bvc_stream_codec_create(const bvc_model *m, int32_t B, int32_t hop_samples, 
     st->fill = c.pad_left;                                   // room for the left reflect padding of frame 0
     StreamDev init{st->fill, {0, 0, 0}};
     BVC_HIP_TRY(hipMemcpy(st->d_state, &init, sizeof(init), hipMemcpyHostToDevice));
-    if ((rc = bvc_vocoder_stream_create(m, B, st->kmax, &st->voc))) return rc;
     { const char *ng = getenv("BVC_STREAM_NO_GRAPH"); st->use_graph = !(ng && ng[0] == '1'); }
     { const char *tf = getenv("BVC_STREAM_FLOW"); st->tick_flow = !(tf && tf[0] == '0'); }
+    // ticks that are launched eagerly (persistent recurrence) let the generator's windows slide through their buffers instead of moving
+    // every history back after every hop (56 us of a 1.5 ms tick at 256 streams); BVC_STREAM_SLIDE=0: never
+    const char *sl = getenv("BVC_STREAM_SLIDE");
+    const bool slide = st->tick_flow && flow_chains_static(m, B) != 0 && !(sl && sl[0] == '0');
+    if ((rc = vocoder_stream_create(m, B, st->kmax, slide, &st->voc))) return rc;
     BVC_HIP_TRY(hipDeviceSynchronize());
     *out = st.release();
     return BVC_OK;
@@ -2105,7 +2139,7 @@ int bvc_stream_codec_tick(bvc_stream_codec *st, int32_t *n_frames, void *stream)
         // side (1.68 eager / 1.70 replayed; the replay only saves host time).  Otherwise (recurrence = layers, no resident grid,
         // BVC_STREAM_FLOW=0) the warm tick is one hipGraph of launch-per-layer kernels as before.  Same bits either way.
         const bool tick_flow = st->tick_flow && flow_chains_static(st->m, B) != 0;
-        const bool warm = !tick_flow && st->use_graph && s != nullptr && st->frames >= STREAM_WARM_FRAMES;     // (the default stream cannot be captured)
+        const bool warm = !tick_flow && !st->voc->slide && st->use_graph && s != nullptr && st->frames >= STREAM_WARM_FRAMES;     // (the default stream cannot be captured)
         g_stream_tick = true; g_tick_flow = tick_flow;
         if (!warm) {
             rc = stream_tick_body(st, k, s);
