@@ -140,6 +140,9 @@ struct FlowWg {
 //   BVC_FLOW_MAXCHK       1 (default): "does a fetched block still hold the sentinel" as an unsigned maximum over the block's dwords (two v_max3_u32 and a
 //                         compare per 16 bytes instead of four compares and three ors); nothing but the sentinel itself may then lie at or above
 //                         it: publishable() maps every such bit pattern (negative NaNs with an all-ones payload top) to the canonical NaN
+#ifndef BVC_CHAIN_G
+#define BVC_CHAIN_G 4           // chains per reduction group of flow_layer_chains (three and more chains per workgroup)
+#endif
 #ifndef BVC_FLOW_MAXCHK
 #define BVC_FLOW_MAXCHK 1
 #endif
@@ -654,7 +657,7 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
     static_assert(PER > 1, "narrow inputs take the per-chain path");
     static_assert(NW == 8, "two sets of four publishing waves");
     constexpr int GM = 4;                                  // at most four chains per reduction group ...
-    const int G = nch >= 3 ? GM : 1;                       // ... and one with two chains per workgroup (measured: 128 x 5 s 6,390 audio-s/s with
+    const int G = nch >= 3 ? BVC_CHAIN_G : 1;              // ... and one with two chains per workgroup (measured: 128 x 5 s 6,390 audio-s/s with
                                                            // one chain per barrier against 6,250 with both behind one; 256 x 5 s 6,790 / 6,960)
     FlowWg &g = c.g;
     const auto &a = *c.a;
@@ -735,6 +738,7 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
                         if (lane == 0) flow_report(g.status, code);
                     }
                 }
+                if (BVC_FLOW_DIAG && k == 0 && g0 == 0 && pass == 1) flow_stamp(c, hopid, 2);     // first chain's operands here
 #pragma unroll
                 for (int u = 0; u < PER; ++u) {
                     const f32x4 xv = __builtin_bit_cast(f32x4, xc[u]);
@@ -747,6 +751,7 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
             }
         }
       }
+        if (BVC_FLOW_DIAG && g0 == 0) flow_stamp(c, hopid, 3);
         if (PRE_OUT && g0 + G >= nch) {                    // the next layer's weights travel during the last group's reduction
             const GPtr ub = uniform_ptr(nxt.w, ((size_t)g.ntile * nxt.wnb + wave * PERN) * g.wmul);
 #pragma unroll
@@ -772,11 +777,13 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
         for (int k = 0; k < GM; ++k)
             if (k < gn) *reinterpret_cast<f32x4 *>(rg + ((k * NW + wave) * 64 + lane) * 4) = accs[k];
         __syncthreads();
+        if (BVC_FLOW_DIAG && g0 == 0) flow_stamp(c, hopid, 4);
         if (pub) {
             const unsigned ytile = (unsigned)((ce.g.mtile * ntiles + g.ntile) * 1024 + lane * 16);
             flow_publish<EPI, ADD, REARM_H, NW>(ce, hopid, rg + pk * (NW * 256), n0, ytile, ntiles, out, bias4, add4, mean4, std4, bitsv);
         }
     }
+    if (BVC_FLOW_DIAG) flow_stamp(c, hopid, 5);
 }
 
 // The GRU cell's reduction and epilogue for ONE chain (c.g.mtile / c.row / c.rowok / c.fr say which): gi / gh are this wave's partial
