@@ -58,12 +58,14 @@ struct CallDesc {
 struct DynPtr {
     float *base;
     int ld;                       // row stride in floats (static / parity kinds)
-    int poff;                     // parity kind: offset added when ((t + toff) & 1)
+    int poff;                     // parity kind: offset added when ((t + toff) & 1); static kind: floats between the frames of a multi-frame launch (GemmParams::frames)
     int meta;                     // kind | packed << 4 | sel << 8 | (toff + 8) << 16
     int dim;                      // frame kind: floats per frame row
 };
 inline int dp_meta(int kind, int packed, int sel, int toff) { return kind | (packed << 4) | (sel << 8) | ((toff + 8) << 16); }
 inline DynPtr dp_static(const float *p, long long ld, int packed = 0) { return DynPtr{const_cast<float *>(p), (int)ld, 0, dp_meta(0, packed, 0, 0), 0}; }
+// static pointer of a launch that covers several frames at once (grid.y = frame): frame f reads / writes base + f * fstride
+inline DynPtr dp_static_frames(const float *p, long long ld, long long fstride, int packed = 0) { return DynPtr{const_cast<float *>(p), (int)ld, (int)fstride, dp_meta(0, packed, 0, 0), 0}; }
 inline DynPtr dp_frame(int sel, int dim, int toff = 0, int packed = 0) { return DynPtr{nullptr, 0, 0, dp_meta(1, packed, sel, toff), dim}; }
 inline DynPtr dp_parity(float *p, long long ld, long long poff, int flip, int packed = 0) { return DynPtr{p, (int)ld, (int)poff, dp_meta(2, packed, 0, flip), 0}; }
 inline DynPtr dp_null() { return DynPtr{nullptr, 0, 0, 0, 0}; }
@@ -122,6 +124,7 @@ struct GemmParams {
     unsigned long long *probe; // in-kernel timing slots, set only in the probe variant of a step graph
     int     node;              // index of this kernel inside its step (probe slot)
     int     tstep;             // static frame offset inside an unrolled multi-step graph: t = desc->t + tstep
+    int     frames;            // > 1: the same layer for several independent frames in ONE launch (grid.y; every pointer static, see dp_static_frames)
 };
 
 int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s, int mtw = 1);

@@ -1235,12 +1235,16 @@ int batched_mlp3(const bvc_model *m, const Workspace &w, const Linear (&l)[3], c
         // a streaming hop (1-2 frames): B*T rows fill a handful of the batched kernel's 128x128 tiles (102 us per 1024^2
         // layer at 256 streams); the recurrent-layer kernel takes the rows of ONE frame (row stride T*K0) in 10 us and
         // writes the fragment-packed frame matrix directly
-        for (int64_t t = 0; t < T; ++t) {
-            if ((rc = launch_gemm_skinny(lin_params(l[0], dp_static(in + t * K0, T * K0), B, dp_static(w.pxC, H, 1)), EPI_ELU, s, m->mtw))) return rc;
-            if ((rc = launch_gemm_skinny(lin_params(l[1], dp_static(w.pxC, H, 1), B, dp_static(w.pxB, H, 1)), EPI_ELU, s, m->mtw))) return rc;
-            if ((rc = launch_gemm_skinny(lin_params(l[2], dp_static(w.pxB, H, 1), B, dp_static(w.pxA + t * (int64_t)mt16 * H, H, 1)), EPI_ELU, s, m->mtw))) return rc;
-        }
-        return BVC_OK;
+        // (all T frames in one launch per layer: the frame is the grid's second dimension)
+        const long long FS = (long long)mt16 * H;
+        auto layer = [&](const Linear &ln, DynPtr x, DynPtr y) {
+            GemmParams p = lin_params(ln, x, B, y);
+            p.frames = (int)T;
+            return launch_gemm_skinny(p, EPI_ELU, s, m->mtw);
+        };
+        if ((rc = layer(l[0], dp_static_frames(in, T * K0, K0), dp_static_frames(w.pxC, H, FS, 1)))) return rc;
+        if ((rc = layer(l[1], dp_static_frames(w.pxC, H, FS, 1), dp_static_frames(w.pxB, H, FS, 1)))) return rc;
+        return layer(l[2], dp_static_frames(w.pxB, H, FS, 1), dp_static_frames(w.pxA, H, FS, 1));
     }
     if ((rc = launch_gemm_batched(in, K0, l[0].w, K0, l[0].b, BT, H, K0, 1, w.pxC, H, s))) return rc;
     if ((rc = launch_gemm_batched(w.pxC, H, l[1].w, H, l[1].b, BT, H, H, 1, w.pxB, H, s))) return rc;
@@ -1255,18 +1259,16 @@ int encode_prologue(const bvc_model *m, const Workspace &w, int B, int64_t T, hi
     const int H = m->cfg.h_dim, X = m->cfg.num_mels;
     const int mt16 = ((B + 15) / 16) * 16;
     int rc;
-    if (T <= SMALL_T_FRAMES) {
-        for (int64_t t = 0; t < T; ++t) {
-            float *px = w.pxA + t * (int64_t)mt16 * H;
-            if ((rc = launch_gemm_skinny(lin_params(m->phi_x[0], dp_static(w.yn + t * X, T * X), B, dp_static(w.pxC, H, 1)), EPI_ELU, s, m->mtw))) return rc;
-            if ((rc = launch_gemm_skinny(lin_params(m->phi_x[1], dp_static(w.pxC, H, 1), B, dp_static(w.pxB, H, 1)), EPI_ELU, s, m->mtw))) return rc;
-            if ((rc = launch_gemm_skinny(lin_params(m->phi_x[2], dp_static(w.pxB, H, 1), B, dp_static(px, H, 1)), EPI_ELU, s, m->mtw))) return rc;
-            GemmParams p = lin_params(m->enc[0], dp_static(px, H, 1), B, dp_static(w.part_dec0 + t * H, T * H));
-            p.seg[0] = mkseg(dp_static(px, H, 1), m->enc[0].wp, 2 * H / 16, H, 0);
-            finish(p);
-            if ((rc = launch_gemm_skinny(p, EPI_LINEAR, s, m->mtw))) return rc;
-        }
-        return BVC_OK;
+    if (T <= SMALL_T_FRAMES) {                             // all T frames in one launch per layer: the frame is the grid's second dimension
+        const long long FS = (long long)mt16 * H;
+        auto layer = [&](GemmParams p, int epi) { p.frames = (int)T; return launch_gemm_skinny(p, epi, s, m->mtw); };
+        if ((rc = layer(lin_params(m->phi_x[0], dp_static_frames(w.yn, T * X, X), B, dp_static_frames(w.pxC, H, FS, 1)), EPI_ELU))) return rc;
+        if ((rc = layer(lin_params(m->phi_x[1], dp_static_frames(w.pxC, H, FS, 1), B, dp_static_frames(w.pxB, H, FS, 1)), EPI_ELU))) return rc;
+        if ((rc = layer(lin_params(m->phi_x[2], dp_static_frames(w.pxB, H, FS, 1), B, dp_static_frames(w.pxA, H, FS, 1)), EPI_ELU))) return rc;
+        GemmParams p = lin_params(m->enc[0], dp_static_frames(w.pxA, H, FS, 1), B, dp_static_frames(w.part_dec0, T * H, H));
+        p.seg[0] = mkseg(dp_static_frames(w.pxA, H, FS, 1), m->enc[0].wp, 2 * H / 16, H, 0);
+        finish(p);
+        return layer(p, EPI_LINEAR);
     }
     const int BT = (int)((long long)B * T);
     if ((rc = launch_gemm_batched(w.yn, X, m->phi_x[0].w, X, m->phi_x[0].b, BT, H, X, 1, w.pxC, H, s))) return rc;
@@ -1281,26 +1283,24 @@ int decode_prologue(const bvc_model *m, const Workspace &w, const float *d_codes
     const int H = m->cfg.h_dim, Z = m->cfg.z_dim;
     const int mt16 = ((B + 15) / 16) * 16;
     int rc;
-    if (T <= SMALL_T_FRAMES) {
-        for (int64_t t = 0; t < T; ++t) {
-            float *pz = w.pxA + t * (int64_t)mt16 * H;
-            if ((rc = launch_gemm_skinny(lin_params(m->phi_z[0], dp_static(d_codes + t * Z, T * Z), B, dp_static(w.pxC, H, 1)), EPI_ELU, s, m->mtw))) return rc;
-            if ((rc = launch_gemm_skinny(lin_params(m->phi_z[1], dp_static(w.pxC, H, 1), B, dp_static(w.pxB, H, 1)), EPI_ELU, s, m->mtw))) return rc;
-            if ((rc = launch_gemm_skinny(lin_params(m->phi_z[2], dp_static(w.pxB, H, 1), B, dp_static(pz, H, 1)), EPI_ELU, s, m->mtw))) return rc;
-            GemmParams p = lin_params(m->dec[0], dp_static(pz, H, 1), B, dp_static(w.part_dec0 + t * H, T * H));
-            p.seg[0] = mkseg(dp_static(pz, H, 1), m->dec[0].wp, 2 * H / 16, H, 0);
-            finish(p);
-            if ((rc = launch_gemm_skinny(p, EPI_LINEAR, s, m->mtw))) return rc;
-            GemmParams q;
-            memset(&q, 0, sizeof(q));
-            q.nseg = 1;
-            q.seg[0] = mkseg(dp_static(pz, H, 1), m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0);
-            q.M = B; q.N = 3 * H; q.bias0 = m->b_ih;
-            q.y = dp_static(w.part_gru + t * 3 * H, T * 3 * H);
-            finish(q);
-            if ((rc = launch_gemm_skinny(q, EPI_LINEAR, s, m->mtw))) return rc;
-        }
-        return BVC_OK;
+    if (T <= SMALL_T_FRAMES) {                             // all T frames in one launch per layer: the frame is the grid's second dimension
+        const long long FS = (long long)mt16 * H;
+        auto layer = [&](GemmParams p, int epi) { p.frames = (int)T; return launch_gemm_skinny(p, epi, s, m->mtw); };
+        if ((rc = layer(lin_params(m->phi_z[0], dp_static_frames(d_codes, T * Z, Z), B, dp_static_frames(w.pxC, H, FS, 1)), EPI_ELU))) return rc;
+        if ((rc = layer(lin_params(m->phi_z[1], dp_static_frames(w.pxC, H, FS, 1), B, dp_static_frames(w.pxB, H, FS, 1)), EPI_ELU))) return rc;
+        if ((rc = layer(lin_params(m->phi_z[2], dp_static_frames(w.pxB, H, FS, 1), B, dp_static_frames(w.pxA, H, FS, 1)), EPI_ELU))) return rc;
+        GemmParams p = lin_params(m->dec[0], dp_static_frames(w.pxA, H, FS, 1), B, dp_static_frames(w.part_dec0, T * H, H));
+        p.seg[0] = mkseg(dp_static_frames(w.pxA, H, FS, 1), m->dec[0].wp, 2 * H / 16, H, 0);
+        finish(p);
+        if ((rc = layer(p, EPI_LINEAR))) return rc;
+        GemmParams q;
+        memset(&q, 0, sizeof(q));
+        q.nseg = 1;
+        q.seg[0] = mkseg(dp_static_frames(w.pxA, H, FS, 1), m->w_ih + (size_t)(H / 16) * 256, 2 * H / 16, H, 0);
+        q.M = B; q.N = 3 * H; q.bias0 = m->b_ih;
+        q.y = dp_static_frames(w.part_gru, T * 3 * H, 3 * H);
+        finish(q);
+        return layer(q, EPI_LINEAR);
     }
     const int BT = (int)((long long)B * T);
     if ((rc = launch_gemm_batched(d_codes, Z, m->phi_z[0].w, Z, m->phi_z[0].b, BT, H, Z, 1, w.pxC, H, s))) return rc;

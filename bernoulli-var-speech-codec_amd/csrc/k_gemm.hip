@@ -65,7 +65,7 @@ __device__ __forceinline__ long long sload_i64(const void *p) {
 // operands are all workspace-static never wait for that line.
 __device__ __forceinline__ Resolved resolve(const DynPtr &d, const CallDesc *c, int mt16, int tstep) {
     const int kind = d.meta & 15, packed = (d.meta >> 4) & 1;
-    if (kind == 0) return {d.base, (long long)d.ld, d.base != nullptr, packed};
+    if (kind == 0) return {d.base + (long long)blockIdx.y * d.poff, (long long)d.ld, d.base != nullptr, packed};      // (grid.y: frame of a multi-frame launch; poff 0 otherwise)
     const int toff = ((d.meta >> 16) & 255) - 8;
     const int t = sload_i32(&c->t) + tstep;
     if (kind == 2) return {d.base + (((t + toff) & 1) ? d.poff : 0), (long long)d.ld, true, packed};
@@ -345,7 +345,7 @@ static void launch_skinny_t(const GemmParams &p, int epi, hipStream_t s) {
     const int n_tiles = p.N / 16, m_tiles = (p.M + 15) / 16, m_groups = (m_tiles + MTW - 1) / MTW;
     const int grid = 8 * ((n_tiles + 7) / 8) * m_groups;
     const size_t lds = (size_t)NW * NG * NGRP * MTW * 256 * sizeof(float);
-    hipLaunchKernelGGL((gemm_skinny_kernel<NG, NGRP, NW, U, MTW, GIL>), dim3(grid), dim3(NW * 64), lds, s, p, epi);
+    hipLaunchKernelGGL((gemm_skinny_kernel<NG, NGRP, NW, U, MTW, GIL>), dim3(grid, p.frames > 1 ? p.frames : 1), dim3(NW * 64), lds, s, p, epi);
 }
 
 template <typename K>
@@ -378,6 +378,11 @@ int launch_gemm_skinny(const GemmParams &p, int epi, hipStream_t s, int mtw) {
             return BVC_EINVAL;
         }
         nb += p.seg[i].K / 16;
+    }
+    if (p.frames > 1) {                                      // frames in grid.y: static pointers only (the frame counter of a call descriptor is not advanced per block)
+        bool ok = dp_kind(p.y) == 0 && (dp_kind(p.aux) == 0) && (p.y2.meta & 15) == 0 && (p.y3.meta & 15) == 0 && !p.probe;
+        for (int i = 0; i < p.nseg; ++i) ok = ok && dp_kind(p.seg[i].x) == 0;
+        if (!ok) { set_error("gemm_skinny: a multi-frame launch takes static pointers only"); return BVC_EINVAL; }
     }
     if (nb != p.nb_total) { set_error("gemm_skinny: nb_total %d does not match the segments (%d)", p.nb_total, nb); return BVC_EINVAL; }
     const int m_tiles = (p.M + 15) / 16;
