@@ -194,3 +194,31 @@ def test_whole_hop_codec_equals_offline_and_oracle(model, B, schedule, monkeypat
         ref_wav = oc.decode(r["codes"], L)[:, :256 * F]
         assert float((wav[:2].cpu() - ref_wav).pow(2).mean().sqrt()) < 1e-4
     model.check_status()
+
+
+@pytest.mark.parametrize("B,hop", [(3, 700), (40, 1100), (5, 300), (17, 1500)])
+def test_whole_hop_codec_other_hops_equal_offline(model, B, hop):
+    """Hops other than configs[4]'s 441 samples: 1-5 and more frames per tick (three and four frames go through the recurrent-layer
+    kernel with the frame in the grid's second dimension, five and more through the batched GEMMs), other window capacities of the
+    sliding generator buffers, ticks that complete no frame.  Codes bit for bit the offline ones, waveform within 2e-6."""
+    from bvcodec import synth
+    from bvcodec.streaming import StreamingCodec
+    hops = max(24, 22050 * 2 // hop)
+    L = hop * hops
+    x = synth.synthetic_speech(B, L, seed=31, kind="speech").to(DEV)
+    sc = StreamingCodec(model, B, 3000, hop=hop)
+    codes, wavs, ks = [], [], set()
+    for i in range(hops):
+        c, w = sc.push(x[:, i * hop:(i + 1) * hop])
+        ks.add(c.shape[1])
+        codes.append(c.clone())
+        wavs.append(w.clone())
+    torch.cuda.synchronize()
+    codes, wav = torch.cat(codes, 1), torch.cat(wavs, 1)
+    F = codes.shape[1]
+    assert F == (L - 768) // 256 + 1 and wav.shape[1] == 256 * F and len(ks) >= 2
+    codes_off = model.encode(x, 3000)
+    assert torch.equal(codes, codes_off[:, :F])
+    wav_off = model.decode(codes_off, L)
+    assert (wav - wav_off[:, :256 * F]).abs().max().item() <= 2e-6
+    model.check_status()
