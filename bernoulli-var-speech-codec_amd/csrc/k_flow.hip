@@ -140,6 +140,9 @@ struct FlowWg {
 //   BVC_FLOW_MAXCHK       1 (default): "does a fetched block still hold the sentinel" as an unsigned maximum over the block's dwords (two v_max3_u32 and a
 //                         compare per 16 bytes instead of four compares and three ors); nothing but the sentinel itself may then lie at or above
 //                         it: publishable() maps every such bit pattern (negative NaNs with an all-ones payload top) to the canonical NaN
+#ifndef BVC_CHAIN_SPEC
+#define BVC_CHAIN_SPEC 0        // flow_layer_chains: the first chain's operand blocks are requested without polling their flags first
+#endif
 #ifndef BVC_CHAIN_G
 #define BVC_CHAIN_G 4           // chains per reduction group of flow_layer_chains (three and more chains per workgroup)
 #endif
@@ -707,7 +710,13 @@ __device__ __forceinline__ void flow_layer_chains(FlowCtx &c, int hopid, const F
         // the first chain of this pass (of this group): wait for its producers, request its blocks
         if (TWO || g0 == 0) {
             g.mtile = mt0 + g0;
-            FlowSrc s0 = flow_wait<PER>(g, bufp, nb, kb0, c.give_up, code, spins);
+            FlowSrc s0;
+            if (BVC_CHAIN_SPEC) {                          // no flag poll (a round trip to the fabric): request the blocks, verify them below
+                s0.base = __builtin_amdgcn_readfirstlane(bufp + (unsigned)(g.mtile * nb + kb0) * 1024u);
+                s0.vl = (unsigned)lane * 16u;
+            } else {
+                s0 = flow_wait<PER>(g, bufp, nb, kb0, c.give_up, code, spins);
+            }
             flow_issue<PER>(g, s0, xc);
         }
 #pragma unroll
