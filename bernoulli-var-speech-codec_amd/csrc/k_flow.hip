@@ -140,6 +140,9 @@ struct FlowWg {
 //   BVC_FLOW_MAXCHK       1 (default): "does a fetched block still hold the sentinel" as an unsigned maximum over the block's dwords (two v_max3_u32 and a
 //                         compare per 16 bytes instead of four compares and three ors); nothing but the sentinel itself may then lie at or above
 //                         it: publishable() maps every such bit pattern (negative NaNs with an all-ones payload top) to the canonical NaN
+#ifndef BVC_FLOW_SPEC
+#define BVC_FLOW_SPEC 0         // lin_segment: 1 = operand blocks requested without polling their flags first (verified and requested again while one holds the sentinel)
+#endif
 #ifndef BVC_CHAIN_SPEC
 #define BVC_CHAIN_SPEC 0        // flow_layer_chains: the first chain's operand blocks are requested without polling their flags first
 #endif
@@ -244,7 +247,13 @@ __device__ __forceinline__ void lin_segment(const FlowWg &g, const float *w, int
         for (int u = 0; u < PER; ++u) wv[u] = wload(ub, (unsigned)g.lane * 16u, u);
     }
     unsigned spins = 0;
-    const FlowSrc src = flow_wait<PER>(g, buf, nb, kb0, give_up, code, spins);
+    FlowSrc src;
+    if (BVC_FLOW_SPEC) {                                   // no flag poll: the blocks themselves are requested until none holds the sentinel
+        src.base = __builtin_amdgcn_readfirstlane(buf + (unsigned)(g.mtile * nb + kb0) * 1024u);
+        src.vl = (unsigned)g.lane * 16u;
+    } else {
+        src = flow_wait<PER>(g, buf, nb, kb0, give_up, code, spins);
+    }
     if (BVC_FLOW_DIAG && hk.st_flags) *hk.st_flags = __builtin_amdgcn_s_memrealtime();
     const f32x4 acc_in = acc;
     u32x4 xr[PER];
