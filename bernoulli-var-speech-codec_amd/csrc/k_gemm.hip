@@ -63,9 +63,11 @@ __device__ __forceinline__ long long sload_i64(const void *p) {
 
 // The frame counter is read from the descriptor only by pointers that need it (kind 1/2): layers whose
 // operands are all workspace-static never wait for that line.
+// MF: the launch covers several frames (grid.y = frame): static pointers advance by their frame stride (other launches never read blockIdx.y)
+template <bool MF = false>
 __device__ __forceinline__ Resolved resolve(const DynPtr &d, const CallDesc *c, int mt16, int tstep) {
     const int kind = d.meta & 15, packed = (d.meta >> 4) & 1;
-    if (kind == 0) return {d.base + (long long)blockIdx.y * d.poff, (long long)d.ld, d.base != nullptr, packed};      // (grid.y: frame of a multi-frame launch; poff 0 otherwise)
+    if (kind == 0) return {MF ? d.base + (long long)blockIdx.y * d.poff : d.base, (long long)d.ld, d.base != nullptr, packed};
     const int toff = ((d.meta >> 16) & 255) - 8;
     const int t = sload_i32(&c->t) + tstep;
     if (kind == 2) return {d.base + (((t + toff) & 1) ? d.poff : 0), (long long)d.ld, true, packed};
@@ -93,7 +95,7 @@ __device__ __forceinline__ void store_out(const Resolved &y, int m, int n, float
 // parity-indexed activation pointer needs the frame counter from the call descriptor (a dependent
 // load of a line another kernel has just written), whose latency is thus hidden behind the weights.
 // MTW row tiles share every weight fragment in registers (weights cross the L2->CU path once per MTW*16 rows).
-template <int NG, int U, int MTW>
+template <int NG, int U, int MTW, bool MF = false>
 __device__ __forceinline__ void run_segment(const float *wl, long long gate_stride, long long kbs, const DynPtr &xd,
                                             const CallDesc *dsc, int mt16, int tstep, const int (&mtile)[MTW],
                                             const int (&xrow)[MTW], int lane, int g, int lo, int hi,
@@ -102,7 +104,7 @@ __device__ __forceinline__ void run_segment(const float *wl, long long gate_stri
     int xstep = 0;
     bool have_x = false;
     auto resolve_x = [&]() {
-        const Resolved x = resolve(xd, dsc, mt16, tstep);
+        const Resolved x = resolve<MF>(xd, dsc, mt16, tstep);
 #pragma unroll
         for (int j = 0; j < MTW; ++j) {
             if (x.packed) { xl[j] = x.p + (long long)mtile[j] * (x.ld >> 4) * 256 + lane * 4; xstep = 256; }
@@ -152,7 +154,7 @@ __device__ __forceinline__ void run_segment(const float *wl, long long gate_stri
     }
 }
 
-template <int NG, int NGRP, int NW, int U, int MTW, bool GIL = false>
+template <int NG, int NGRP, int NW, int U, int MTW, bool GIL = false, bool MF = false>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int epi) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][NGRP*NG][MTW][256]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -214,12 +216,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             const long long gate_stride = GIL ? 256 : (long long)(p.gate_rows >> 4) * p.seg[s].wnb * 256;
             const float *wl = p.seg[s].w + (long long)ntile * p.seg[s].wnb * kbs + lane * 4;
             if constexpr (NGRP == 1) {
-                run_segment<NG, U, MTW>(wl, gate_stride, kbs, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
+                run_segment<NG, U, MTW, MF>(wl, gate_stride, kbs, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
             } else {
                 if (p.seg[s].grp == 0)
-                    run_segment<NG, U, MTW>(wl, gate_stride, kbs, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
+                    run_segment<NG, U, MTW, MF>(wl, gate_stride, kbs, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc0);
                 else
-                    run_segment<NG, U, MTW>(wl, gate_stride, kbs, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc1);
+                    run_segment<NG, U, MTW, MF>(wl, gate_stride, kbs, p.seg[s].x, dsc, mt16, p.tstep, mtile, xrow, lane, g, lo, hi, acc1);
             }
         }
     }
@@ -252,17 +254,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             for (int w = 1; w < NW; ++w) sum += red[((w * NACC + a) * MTW + j) * 256 + tid];
             v[a] = sum + bias[a];
         }
-        const Resolved y = resolve(p.y, dsc, mt16, p.tstep);
+        const Resolved y = resolve<MF>(p.y, dsc, mt16, p.tstep);
         if (epi == EPI_LINEAR || epi == EPI_ELU) {
             float o = v[0];
             if (p.aux.base || (p.aux.meta & 15)) {                            // pre-computed half of a split dot product
-                const Resolved ad = resolve(p.aux, dsc, mt16, p.tstep);
+                const Resolved ad = resolve<MF>(p.aux, dsc, mt16, p.tstep);
                 o += ad.p[(long long)m * ad.ld + n];
             }
             if (epi == EPI_ELU) o = elu1(o);
             store_out(y, m, n, o);
             if (p.y2.meta & 15) {                                             // a second copy (the folded hop keeps ELU(dec.4) of every frame)
-                const Resolved y2 = resolve(p.y2, dsc, mt16, p.tstep);
+                const Resolved y2 = resolve<MF>(p.y2, dsc, mt16, p.tstep);
                 if (y2.ok) store_out(y2, m, n, o);
             }
         } else if (epi == EPI_SIGMOID) {
@@ -275,23 +277,23 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             } else {                                                 // BVRNN.forward: straight-through forward value
                 float arg = pr;
                 if (p.sample == CS_SAMPLE) {
-                    const Resolved un = resolve(p.y2, dsc, mt16, p.tstep);
+                    const Resolved un = resolve<MF>(p.y2, dsc, mt16, p.tstep);
                     arg = __fadd_rn(__fsub_rn(un.p[(long long)m * un.ld + n], 0.5f), pr);     // (u - 0.5) + p
                 }
                 z = __fadd_rn(__fsub_rn(rintf(arg), pr), pr);        // round(.) - p + p
             }
             if (p.var_bit) {
-                const Resolved bt = resolve(p.aux, dsc, mt16, p.tstep);
+                const Resolved bt = resolve<MF>(p.aux, dsc, mt16, p.tstep);
                 const float bits = bt.p[(long long)m * bt.ld];
                 z = (bits > (float)n) ? z : (z != z ? z : 0.5f);     // z*m + 0.5*(1-m): a NaN stays a NaN under the mask too (NaN * 0)
             }
             store_out(y, m, n, z);
-            const Resolved y3 = resolve(p.y3, dsc, mt16, p.tstep);
+            const Resolved y3 = resolve<MF>(p.y3, dsc, mt16, p.tstep);
             if (y3.ok) store_out(y3, m, n, pr);
         } else if (epi == EPI_MEL) {
             const float d = v[0];
             if (y.ok) store_out(y, m, n, d);
-            const Resolved y2 = resolve(p.y2, dsc, mt16, p.tstep);
+            const Resolved y2 = resolve<MF>(p.y2, dsc, mt16, p.tstep);
             store_out(y2, m, n, (d - p.mean[n]) / p.stdv[n]);
         } else if (epi == EPI_GRU_PART) {
           if constexpr (NG == 3 && NGRP == 1) {
@@ -304,11 +306,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             const float rg = sigmoid1(ph[0] + gi_r);
             const float zg = sigmoid1(ph[H] + gi_z);
             const float ng = tanhf(gi_n + rg * ph[2 * H]);
-            const Resolved hprev = resolve(p.aux, dsc, mt16, p.tstep);
+            const Resolved hprev = resolve<MF>(p.aux, dsc, mt16, p.tstep);
             const float hp = hprev.packed ? hprev.p[packed_off(m, n, hprev.ld)] : hprev.p[(long long)m * hprev.ld + n];
             const float hn = (hp - ng) * zg + ng;
             store_out(y, m, n, hn);
-            const Resolved y2 = resolve(p.y2, dsc, mt16, p.tstep);
+            const Resolved y2 = resolve<MF>(p.y2, dsc, mt16, p.tstep);
             if (y2.ok) store_out(y2, m, n, hn);
           }
         } else if (epi == EPI_GRU) {
@@ -316,18 +318,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmParams p, int 
             float gi_r = v[0], gi_z = v[1], gi_n = v[2];
             const float gh_r = v[3], gh_z = v[4], gh_n = v[5];
             if (p.y3.meta & 15) {                                            // W_ih[:, H:] phi_z + b_ih, batched over all frames
-                const Resolved pg = resolve(p.y3, dsc, mt16, p.tstep);
+                const Resolved pg = resolve<MF>(p.y3, dsc, mt16, p.tstep);
                 const float *q = pg.p + (long long)m * pg.ld + n;
                 gi_r += q[0]; gi_z += q[p.gate_rows]; gi_n += q[2 * p.gate_rows];
             }
             const float rg = sigmoid1(gh_r + gi_r);
             const float zg = sigmoid1(gh_z + gi_z);
             const float ng = tanhf(gi_n + rg * gh_n);
-            const Resolved hprev = resolve(p.aux, dsc, mt16, p.tstep);
+            const Resolved hprev = resolve<MF>(p.aux, dsc, mt16, p.tstep);
             const float hp = hprev.packed ? hprev.p[packed_off(m, n, hprev.ld)] : hprev.p[(long long)m * hprev.ld + n];
             const float hn = (hp - ng) * zg + ng;
             store_out(y, m, n, hn);
-            const Resolved y2 = resolve(p.y2, dsc, mt16, p.tstep);
+            const Resolved y2 = resolve<MF>(p.y2, dsc, mt16, p.tstep);
             if (y2.ok) store_out(y2, m, n, hn);
           }
         }
@@ -345,7 +347,8 @@ static void launch_skinny_t(const GemmParams &p, int epi, hipStream_t s) {
     const int n_tiles = p.N / 16, m_tiles = (p.M + 15) / 16, m_groups = (m_tiles + MTW - 1) / MTW;
     const int grid = 8 * ((n_tiles + 7) / 8) * m_groups;
     const size_t lds = (size_t)NW * NG * NGRP * MTW * 256 * sizeof(float);
-    hipLaunchKernelGGL((gemm_skinny_kernel<NG, NGRP, NW, U, MTW, GIL>), dim3(grid, p.frames > 1 ? p.frames : 1), dim3(NW * 64), lds, s, p, epi);
+    if (p.frames > 1) hipLaunchKernelGGL((gemm_skinny_kernel<NG, NGRP, NW, U, MTW, GIL, true>), dim3(grid, p.frames), dim3(NW * 64), lds, s, p, epi);
+    else              hipLaunchKernelGGL((gemm_skinny_kernel<NG, NGRP, NW, U, MTW, GIL>), dim3(grid), dim3(NW * 64), lds, s, p, epi);
 }
 
 template <typename K>
