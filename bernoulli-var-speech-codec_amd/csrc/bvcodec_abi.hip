@@ -1,6 +1,7 @@
 // C ABI of libbvcodec_hip.so (include/bvcodec.h): model creation (weight upload + re-layout into
 // MFMA fragment order), workspace carving and the per-call kernel schedules of the
 // BVRNNCodecModel encode/decode path.  Host-side only; the kernels are in k_*.hip.
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -1592,7 +1593,7 @@ struct bvc_vocoder_stream {
     const bvc_model *m = nullptr;
     int B = 0, kmax = 0, parity = 0;
     // slide: ONE buffer per tensor with room for cap_frames frames; the window of a hop starts `cursor` frames into it and the history is
-    // moved back to the front only when the room is used up (every cap_frames / kmax hops at least) instead of after every hop.  The
+    // moved back to the front only when the room is used up (every cap_frames / kmax - 1 hops at least) instead of after every hop.  The
     // addresses of a hop then change from hop to hop: not for a hop that is replayed from a graph (bvc_stream_codec's eager ticks only).
     bool slide = false;
     int cursor = 0, cap_frames = 0;
@@ -1986,7 +1987,9 @@ static int vocoder_stream_create(const bvc_model *m, int32_t B, int32_t max_fram
     std::unique_ptr<bvc_vocoder_stream> st(new bvc_vocoder_stream());
     st->m = m; st->B = B; st->kmax = max_frames_per_push;
     st->slide = slide;
-    st->cap_frames = slide ? 16 * max_frames_per_push : max_frames_per_push;      // frames of room behind the history
+    // frames of room behind the history: 32 (16 hops of one or two frames between two moves of the histories; 2.2 GB of buffers at 256 streams),
+    // more only where longer hops need it
+    st->cap_frames = slide ? std::max(2 * max_frames_per_push + 8, 32) : max_frames_per_push;
     const long long room = st->cap_frames;
     auto mk = [&](int C, int H, int r) { StreamTensor t; t.buf[0] = t.buf[1] = nullptr; t.C = C; t.H = H; t.rate = r; t.rows = H + (long long)r * room; return t; };
     st->mel = mk(c.num_mels, (m->conv_pre.ks - 1) * m->conv_pre.dil, 1);
