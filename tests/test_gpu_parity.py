@@ -588,6 +588,27 @@ def test_nonzero_initial_state_and_returned_state(env):
     assert np.abs(hT[0].cpu().numpy() - r["h_last"].numpy()).max() < 5e-6
 
 
+def test_initial_state_at_any_alignment(env):
+    """The persistent launch takes its initial state, the sentinel fill and its arguments from ONE preparation kernel when the state is
+    16-byte aligned, from three separate kernels when it is not (a C caller may pass any float pointer): same bits, and the state after
+    the last frame continues a split sequence exactly."""
+    model = env[0]
+    rng = np.random.default_rng(5)
+    B, T = 7, 11
+    z = torch.from_numpy(rng.integers(0, 2, size=(B, T, 64)).astype(np.float32)).to(DEV)
+    h0 = torch.from_numpy((0.3 * rng.standard_normal((B, 1024))).astype(np.float32)).to(DEV)
+    buf = torch.empty(B * 1024 + 1, device=DEV)
+    h0_odd = buf[1:].view(B, 1024)
+    h0_odd.copy_(h0)
+    assert h0.data_ptr() % 16 == 0 and h0_odd.data_ptr() % 16 == 4 and h0_odd.is_contiguous()
+    mel_a, hT_a = model.bvrnn.decode(z, h0.unsqueeze(0))
+    mel_b, hT_b = model.bvrnn.decode(z, h0_odd.unsqueeze(0))
+    assert torch.equal(mel_a, mel_b) and torch.equal(hT_a, hT_b)
+    mel_1, h_mid = model.bvrnn.decode(z[:, :4].contiguous(), h0.unsqueeze(0))
+    mel_2, hT_c = model.bvrnn.decode(z[:, 4:].contiguous(), h_mid)
+    assert torch.equal(torch.cat([mel_1, mel_2], 1), mel_a) and torch.equal(hT_c, hT_a)
+
+
 def test_execution_variants_agree(env):
     """The hipGraph-replayed default, the eager fallback (BVC_NO_GRAPH=1, what the library falls back to
     when stream capture is unavailable) and the unfused vocoder (BVC_UNFUSED_AMP=1) run the same
