@@ -13,9 +13,19 @@ constexpr int AUX_SC1 = 16;
 
 // MODE 0: poll the flag dword, then fetch the block (what the kernel does); 1: poll only (no block fetch); 2: fetch the block as the poll
 template <int MODE>
-__global__ __launch_bounds__(64) void pingpong(unsigned *buf, int peer, int rounds, unsigned long long *out, unsigned spin_limit) {
+__global__ __launch_bounds__(64) void pingpong(unsigned *buf, int peer, int rounds, unsigned long long *out, unsigned spin_limit, int npoll) {
     const int bid = blockIdx.x;
-    if (bid != 0 && bid != peer) return;
+    if (bid != 0 && bid != peer) {
+        // bystanders (npoll of them): follow workgroup 0's flag like the consumers of a layer's block that are not on the critical path here
+        if (bid > npoll) return;
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(buf, 0, 2 * 1024, 0x00020000);
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned t = __builtin_amdgcn_raw_buffer_load_b32(rs0, 63u * 16u + 12u, 0u, AUX_SC1);
+            asm volatile("" ::: "memory");
+            if (t >= (unsigned)rounds || ++spins > spin_limit) return;
+        }
+    }
     const bool is_a = bid == 0;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(buf, 0, 2 * 1024, 0x00020000);
     const unsigned lane = threadIdx.x;
@@ -66,9 +76,9 @@ int main() {
     for (int mode = 0; mode < 3; ++mode)
         for (int peer : {8, 1, 2, 3, 4, 5, 6, 7}) {       // 8: the same XCD as workgroup 0; 1..7: XCD 1..7
             CK(hipMemset(buf, 0, 2048)); CK(hipMemset(out, 0, 24));
-            if (mode == 0) hipLaunchKernelGGL(pingpong<0>, dim3(16), dim3(64), 0, 0, buf, peer, rounds, out, 1000000u);
-            if (mode == 1) hipLaunchKernelGGL(pingpong<1>, dim3(16), dim3(64), 0, 0, buf, peer, rounds, out, 1000000u);
-            if (mode == 2) hipLaunchKernelGGL(pingpong<2>, dim3(16), dim3(64), 0, 0, buf, peer, rounds, out, 1000000u);
+            if (mode == 0) hipLaunchKernelGGL(pingpong<0>, dim3(16), dim3(64), 0, 0, buf, peer, rounds, out, 1000000u, 0);
+            if (mode == 1) hipLaunchKernelGGL(pingpong<1>, dim3(16), dim3(64), 0, 0, buf, peer, rounds, out, 1000000u, 0);
+            if (mode == 2) hipLaunchKernelGGL(pingpong<2>, dim3(16), dim3(64), 0, 0, buf, peer, rounds, out, 1000000u, 0);
             CK(hipDeviceSynchronize());
             unsigned long long h[3];
             CK(hipMemcpy(h, out, 24, hipMemcpyDeviceToHost));
@@ -76,5 +86,16 @@ int main() {
             const double us = (double)h[0] / (double)rate * 1e3 / (rounds - 1);
             printf("%-52s  workgroup 0 (XCD 0) <-> workgroup %d (XCD %d): %.3f us per round = %.3f us per hand-off\n", names[mode], peer, peer % 8, us, us / 2);
         }
+    // the same hand-off (workgroup 0 <-> workgroup 1, XCD 1) while `npoll` other workgroups poll workgroup 0's flag too
+    for (int npoll : {0, 7, 15, 63, 127, 255}) {
+        CK(hipMemset(buf, 0, 2048)); CK(hipMemset(out, 0, 24));
+        hipLaunchKernelGGL(pingpong<0>, dim3(256), dim3(64), 0, 0, buf, 1, rounds, out, 4000000u, npoll);
+        CK(hipDeviceSynchronize());
+        unsigned long long h[3];
+        CK(hipMemcpy(h, out, 24, hipMemcpyDeviceToHost));
+        if (h[2]) { printf("npoll %d: timed out\n", npoll); continue; }
+        const double us = (double)h[0] / (double)rate * 1e3 / (rounds - 1);
+        printf("flag poll, then block fetch, %3d bystanders polling the same flag: %.3f us per round = %.3f us per hand-off\n", npoll, us, us / 2);
+    }
     return 0;
 }
